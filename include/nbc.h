@@ -1,0 +1,163 @@
+/*
+ * nbc.h -- C ABI of the MI355X-native FCN-ResNet-50 segmentation path ("nbc" = neural bark
+ * calculator).  One shared library, libnbc_hip.so, plain pointers and sizes only; no torch
+ * types.  All file:line citations are into /root/reference/src/bark_calculator/.
+ *
+ * What this boundary replaces in the reference:
+ *   - the object bound to `self.model`            models.py:221   fcn_resnet50(pretrained=False)
+ *   - `self.model.load_state_dict(...)`           models.py:222   -> nbc_pack_weights / nbc_load_weights
+ *   - `self.model.to(device)`                     models.py:223   -> nbc_create(device) + nbc_attach_weights
+ *   - `outputs = self.model(batch[0].to(device))` models.py:269   -> nbc_forward (logits_full_dev)
+ *   - `outputs = torch.argmax(outputs, dim=1)`    models.py:270   -> nbc_forward (labels_dev)
+ *   - the `--exclude_nodes` remap 2 -> 1          models.py:273-276 -> nbc_forward (exclude_nodes)
+ *   - the per-class pixel counting                models.py:324-331 -> nbc_forward (counts_dev)
+ *   - ToTensor + Normalize of the loaded image    dataset.py:175-186, models.py:233-237
+ *                                                 -> nbc_forward with NBC_IN_U8_NHWC
+ *
+ * Conventions: every function returns 0 (NBC_OK) or a negative error code; the message of the
+ * last error on the calling thread is nbc_last_error().  Nothing throws across the ABI.  A
+ * context is bound to one HIP device and is not thread-safe (the reference loop is
+ * single-threaded, models.py:257-270).  The caller owns every input/output buffer; the context
+ * owns its activation workspace (sized on the first call for an (N,H,W), then reused: no
+ * allocation in steady state).  Work is enqueued on the caller's stream; outputs are valid
+ * once that stream has been synchronised.
+ *
+ * Eval-mode only: BatchNorm uses running statistics, Dropout is the identity.
+ */
+#ifndef NBC_H
+#define NBC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbc_ctx nbc_ctx;
+
+enum {
+  NBC_OK = 0,
+  NBC_ERR_INVALID = -1,   /* bad argument / shape */
+  NBC_ERR_KEYS = -2,      /* state_dict keys or shapes do not match (models.py:222 would raise) */
+  NBC_ERR_HIP = -3,       /* HIP runtime error */
+  NBC_ERR_STATE = -4,     /* call order (e.g. forward before weights) */
+  NBC_ERR_NOMEM = -5
+};
+
+/* Arithmetic of the convolution stack. */
+enum {
+  NBC_PREC_FP32 = 0,  /* f32 activations/weights, v_mfma_f32_32x32x2_f32: the parity mode */
+  NBC_PREC_BF16 = 1   /* bf16 activations/weights, f32 accumulate + f32 BN epilogue: throughput mode */
+};
+
+/* Layout of the image handed to nbc_forward. */
+enum {
+  NBC_IN_F32_NCHW = 0,  /* float32 [N,3,H,W], already normalised: exactly `batch[0]` of models.py:269 */
+  NBC_IN_U8_NHWC = 1    /* uint8 [N,H,W,3] RGB as decoded by pil_loader (dataset.py:82-90); the
+                           library applies ToTensor (/255) and Normalize((x-mean)/std) in f32 */
+};
+
+enum {
+  NBC_LABEL_U8 = 0,   /* uint8 [N,H,W]  */
+  NBC_LABEL_I64 = 1   /* int64 [N,H,W]: dtype of torch.argmax at models.py:270 */
+};
+
+/* One entry of a state_dict (models.py:222).  `data` is HOST memory, C-contiguous. */
+typedef struct {
+  const char* name;   /* e.g. "backbone.layer1.0.conv1.weight" */
+  const void* data;
+  int64_t shape[4];
+  int32_t ndim;
+  int32_t dtype;      /* 0 = float32, 1 = int64 (num_batches_tracked: checked for presence, unused) */
+} nbc_tensor;
+
+/* One convolution unit of the network, in execution order (introspection / tests). */
+typedef struct {
+  char name[64];      /* state_dict prefix of the conv */
+  char bn[64];        /* state_dict prefix of its BatchNorm, "" for classifier.4 */
+  int32_t cin, cout, k, stride, pad, dil;
+  int32_t relu, bias, residual;
+} nbc_conv_desc;
+
+/* Per-launch record of the last profiled forward (nbc_set_profiling). */
+typedef struct {
+  char name[64];      /* conv unit name, or "ingest" / "maxpool" / "upsample_argmax" */
+  char kernel[32];    /* kernel family: "conv_igemm", "head1x1", ... */
+  float ms;           /* HIP-event time around the launch on the forward's stream */
+  double flops;       /* algorithmic: 2*MAC of the convolution (0 for non-conv ops) */
+  double bytes;       /* algorithmic: input read once + weights once + output once (+ identity) */
+  int32_t kh, kw;     /* kernel extent (0 for non-conv) */
+} nbc_op_record;
+
+const char* nbc_last_error(void);
+const char* nbc_version(void);
+
+/* ---- topology introspection (no GPU needed) ------------------------------------------- */
+int nbc_num_convs(void);
+int nbc_conv_info(int index, nbc_conv_desc* out);
+int nbc_num_state_keys(void);                               /* 326 */
+int nbc_state_key(int index, const char** name, int64_t shape[4], int32_t* ndim, int32_t* dtype);
+/* Low-resolution logits size for an HxW input (three stride-2 stages). */
+int nbc_lowres_size(int H, int W, int* h, int* w);
+
+/* ---- weights (host side; no GPU needed) ------------------------------------------------ */
+/* Size in bytes of the packed weight blob for a precision (same on every rank). */
+size_t nbc_packed_weights_bytes(int precision);
+/* Strict key/shape check like nn.Module.load_state_dict (models.py:222): NBC_ERR_KEYS with a
+ * message listing missing / unexpected / mis-shaped entries.  Folds each BatchNorm into an f32
+ * (scale, shift) pair, reorders conv weights OIHW -> [O][kh][kw][I] (K-major panels, zero padded
+ * to whole 128-byte K-steps), converts to the precision's element type, writes `blob`. */
+int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob, size_t blob_bytes);
+
+/* ---- context --------------------------------------------------------------------------- */
+int nbc_create(nbc_ctx** out, int hip_device);
+int nbc_destroy(nbc_ctx* ctx);
+/* Attach a packed blob that already lives in DEVICE memory and stays owned by the caller
+ * (e.g. a torch tensor that was the target of an RCCL broadcast).  Must outlive the context
+ * or the next attach. */
+int nbc_attach_weights(nbc_ctx* ctx, const void* dev_blob, size_t bytes, int precision);
+/* Convenience: pack on the host, allocate device memory owned by the context, upload. */
+int nbc_load_weights(nbc_ctx* ctx, const nbc_tensor* tensors, int n, int precision);
+/* mean/std used for NBC_IN_U8_NHWC input; defaults are models.py:208-209. */
+int nbc_set_normalization(nbc_ctx* ctx, const float mean[3], const float std[3]);
+/* Pre-size the workspace for an (N,H,W) so that the first nbc_forward does not allocate. */
+int nbc_reserve(nbc_ctx* ctx, int N, int H, int W);
+
+/* ---- the hot path ------------------------------------------------------------------------
+ * x_dev                 device pointer, layout per x_dtype
+ * logits_lowres_dev     nullable, float32 [N,3,h,w] (output of classifier.4, models.py:121)
+ * logits_full_dev       nullable, float32 [N,3,H,W] (what self.model(x) returns, models.py:269)
+ * labels_dev            nullable, [N,H,W] per labels_dtype (models.py:270; ties -> lowest index,
+ *                       NaN counts as the maximum, like torch.argmax)
+ * counts_dev            nullable, int64 [N,3]: pixels per class after the optional remap
+ * exclude_nodes         non-zero: label 2 -> 1 after the argmax (models.py:273-276)
+ * hip_stream            hipStream_t (NULL = default stream)
+ */
+int nbc_forward(nbc_ctx* ctx, const void* x_dev, int x_dtype, int N, int H, int W,
+                float* logits_lowres_dev, float* logits_full_dev,
+                void* labels_dev, int labels_dtype, int64_t* counts_dev,
+                int exclude_nodes, void* hip_stream);
+
+/* The tail of the path on its own: bicubic upsample (models.py:38-41) of caller-supplied
+ * low-resolution logits float32 [N,3,h,w] to HxW + argmax (models.py:270) + remap + counts.
+ * Same output arguments as nbc_forward.  Used to test tie / NaN behaviour with crafted logits. */
+int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int h, int w, int H, int W,
+                        float* logits_full_dev, void* labels_dev, int labels_dtype,
+                        int64_t* counts_dev, int exclude_nodes, void* hip_stream);
+
+/* ---- debugging / measurement ----------------------------------------------------------- */
+/* Copy the activation written by conv unit `name` during the last forward to `dst_host` as
+ * float32 NCHW.  `capacity` is in elements.  Only valid when keep-activations is on. */
+int nbc_set_keep_activations(nbc_ctx* ctx, int on);
+int nbc_read_activation(nbc_ctx* ctx, const char* name, float* dst_host, size_t capacity,
+                        int64_t shape[4]);
+/* When on, every launch of the next forwards is bracketed by HIP events on the stream. */
+int nbc_set_profiling(nbc_ctx* ctx, int on);
+int nbc_num_op_records(nbc_ctx* ctx);
+int nbc_get_op_record(nbc_ctx* ctx, int index, nbc_op_record* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBC_H */

@@ -1,0 +1,460 @@
+// Context, launch plan and the forward entry point of libnbc_hip.so.
+//
+// nbc_forward replaces, at the C ABI, `outputs = self.model(batch[0].to(self.device))` followed
+// by `torch.argmax(outputs, dim=1)` (/root/reference/src/bark_calculator/models.py:269-270).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nbc.h"
+#include "nbc_internal.hpp"
+#include "nbc_kernels.hpp"
+#include "nbc_net.hpp"
+
+using namespace nbc;
+
+namespace {
+
+#define NBC_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return set_error(NBC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+enum OpKind { OP_INGEST, OP_CONV, OP_MAXPOOL, OP_HEAD1X1, OP_UPSAMPLE };
+
+struct Op {
+  OpKind kind;
+  int unit;            // conv unit index (OP_CONV / OP_HEAD1X1), -1 otherwise
+  int in_buf, out_buf, res_buf;
+  int Hi, Wi, Ci, Ho, Wo, Co;
+  std::string name;
+  double flops, bytes;
+};
+
+struct Plan {
+  int N = 0, H = 0, W = 0, precision = -1;
+  bool keep = false;
+  int h = 0, w = 0;                    // low-res logits size
+  std::vector<Op> ops;
+  std::vector<size_t> buf_bytes;       // per activation buffer
+};
+
+}  // namespace
+
+struct nbc_ctx {
+  int device = 0;
+  int precision = -1;
+  const unsigned char* weights = nullptr;   // device blob
+  void* owned_weights = nullptr;
+  PackedLayout layout;
+  float mean[3] = {0.7399f, 0.6139f, 0.4401f};   // models.py:208
+  float stdv[3] = {0.1068f, 0.1272f, 0.1271f};   // models.py:209
+  Plan plan;
+  std::vector<void*> bufs;
+  std::vector<size_t> buf_cap;
+  float* lowres = nullptr;
+  size_t lowres_cap = 0;
+  bool keep = false;
+  bool profiling = false;
+  std::vector<hipEvent_t> events;
+  std::vector<nbc_op_record> records;
+  std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
+};
+
+namespace {
+
+// Build the launch list for an (N,H,W).  Activation buffers are recycled through a small pool
+// unless `keep` asks for one buffer per op (layer-by-layer parity tests).
+int build_plan(nbc_ctx* c, int N, int H, int W) {
+  Plan P;
+  P.N = N; P.H = H; P.W = W; P.precision = c->precision; P.keep = c->keep;
+  const int eb = elem_bytes(c->precision);
+  const auto& units = conv_units();
+  const auto& L = c->layout;
+
+  std::vector<bool> in_use;
+  auto acquire = [&](size_t bytes) {
+    if (!P.keep)
+      for (size_t i = 0; i < in_use.size(); ++i)
+        if (!in_use[i]) { in_use[i] = true; P.buf_bytes[i] = std::max(P.buf_bytes[i], bytes); return (int)i; }
+    in_use.push_back(true);
+    P.buf_bytes.push_back(bytes);
+    return (int)in_use.size() - 1;
+  };
+  auto release = [&](int b) { if (b >= 0 && !P.keep) in_use[b] = false; };
+
+  auto conv_out = [](int x, int k, int s, int p, int d) { return (x + 2 * p - d * (k - 1) - 1) / s + 1; };
+
+  // ingest: image -> NHWC with one 16-byte pixel
+  const int cin_img = kChunkBytes / eb;
+  int cur = acquire((size_t)N * H * W * kChunkBytes);
+  {
+    Op o{};
+    o.kind = OP_INGEST; o.unit = -1; o.in_buf = -1; o.out_buf = cur; o.res_buf = -1;
+    o.Hi = H; o.Wi = W; o.Ci = 3; o.Ho = H; o.Wo = W; o.Co = cin_img; o.name = "ingest";
+    P.ops.push_back(o);
+  }
+  int curH = H, curW = W, curC = cin_img;
+
+  auto add_conv = [&](int ui, int in_buf, int inH, int inW, int inC, int res_buf, int* oH, int* oW) {
+    const ConvUnit& u = units[ui];
+    const int Ho = conv_out(inH, u.k, u.stride, u.pad, u.dil);
+    const int Wo = conv_out(inW, u.k, u.stride, u.pad, u.dil);
+    Op o{};
+    o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
+    o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
+    o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
+    const double M = (double)N * Ho * Wo;
+    o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
+    o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +
+               (res_buf >= 0 ? M * u.cout : 0.0)) * eb;
+    P.ops.push_back(o);
+    *oH = Ho; *oW = Wo;
+    return o.out_buf;
+  };
+
+  size_t ui = 0;
+  // stem
+  {
+    int oH, oW;
+    const int b = add_conv(0, cur, curH, curW, curC, -1, &oH, &oW);
+    release(cur);
+    cur = b; curH = oH; curW = oW; curC = units[0].cout;
+    const int pH = (curH - 1) / 2 + 1, pW = (curW - 1) / 2 + 1;
+    Op o{};
+    o.kind = OP_MAXPOOL; o.unit = -1; o.in_buf = cur; o.res_buf = -1;
+    o.Hi = curH; o.Wi = curW; o.Ci = curC; o.Ho = pH; o.Wo = pW; o.Co = curC; o.name = "backbone.maxpool";
+    o.out_buf = acquire((size_t)N * pH * pW * curC * eb);
+    o.bytes = ((double)N * curH * curW * curC + (double)N * pH * pW * curC) * eb;
+    P.ops.push_back(o);
+    release(cur);
+    cur = o.out_buf; curH = pH; curW = pW;
+    ui = 1;
+  }
+  // bottlenecks
+  while (ui < units.size() && units[ui].block_first) {
+    int h1, w1, h2, w2, h3, w3;
+    const int t1 = add_conv((int)ui, cur, curH, curW, curC, -1, &h1, &w1);
+    const int t2 = add_conv((int)ui + 1, t1, h1, w1, units[ui].cout, -1, &h2, &w2);
+    release(t1);
+    int idt = cur;
+    size_t c3 = ui + 2;
+    if (!units[ui + 2].residual) {      // downsample present
+      int hd, wd;
+      idt = add_conv((int)ui + 2, cur, curH, curW, curC, -1, &hd, &wd);
+      release(cur);
+      c3 = ui + 3;
+    }
+    const int out = add_conv((int)c3, t2, h2, w2, units[ui + 1].cout, idt, &h3, &w3);
+    release(t2);
+    release(idt);
+    cur = out; curH = h3; curW = w3; curC = units[c3].cout;
+    ui = c3 + 1;
+  }
+  // head
+  {
+    int oH, oW;
+    const int t = add_conv((int)ui, cur, curH, curW, curC, -1, &oH, &oW);   // classifier.0
+    release(cur);
+    Op o{};
+    o.kind = OP_HEAD1X1; o.unit = (int)ui + 1; o.in_buf = t; o.out_buf = -1; o.res_buf = -1;
+    o.Hi = oH; o.Wi = oW; o.Ci = units[ui].cout; o.Ho = oH; o.Wo = oW; o.Co = kNumClasses;
+    o.name = units[ui + 1].name;
+    o.flops = 2.0 * N * oH * oW * o.Ci * kNumClasses;
+    o.bytes = (double)N * oH * oW * o.Ci * eb + (double)N * oH * oW * kNumClasses * 4;
+    P.ops.push_back(o);
+    release(t);
+    P.h = oH; P.w = oW;
+    Op up{};
+    up.kind = OP_UPSAMPLE; up.unit = -1; up.in_buf = -1; up.out_buf = -1; up.res_buf = -1;
+    up.Hi = oH; up.Wi = oW; up.Ci = kNumClasses; up.Ho = H; up.Wo = W; up.Co = kNumClasses;
+    up.name = "upsample_argmax";
+    up.bytes = (double)N * oH * oW * kNumClasses * 4 + (double)N * H * W;
+    P.ops.push_back(up);
+  }
+  (void)L;
+
+  // (re)allocate buffers
+  if (c->bufs.size() < P.buf_bytes.size()) { c->bufs.resize(P.buf_bytes.size(), nullptr); c->buf_cap.resize(P.buf_bytes.size(), 0); }
+  for (size_t i = 0; i < P.buf_bytes.size(); ++i) {
+    if (c->buf_cap[i] < P.buf_bytes[i]) {
+      if (c->bufs[i]) NBC_HIP(hipFree(c->bufs[i]));
+      c->bufs[i] = nullptr; c->buf_cap[i] = 0;
+      hipError_t e = hipMalloc(&c->bufs[i], P.buf_bytes[i]);
+      if (e != hipSuccess) return set_error(NBC_ERR_NOMEM, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+      c->buf_cap[i] = P.buf_bytes[i];
+    }
+  }
+  const size_t lr = (size_t)N * kNumClasses * P.h * P.w * sizeof(float);
+  if (c->lowres_cap < lr) {
+    if (c->lowres) NBC_HIP(hipFree(c->lowres));
+    c->lowres = nullptr; c->lowres_cap = 0;
+    NBC_HIP(hipMalloc((void**)&c->lowres, lr));
+    c->lowres_cap = lr;
+  }
+  c->act_of.clear();
+  for (size_t i = 0; i < P.ops.size(); ++i) c->act_of[P.ops[i].name] = (int)i;
+  c->plan = P;
+  return NBC_OK;
+}
+
+const char* kernel_name(OpKind k) {
+  switch (k) {
+    case OP_INGEST: return "ingest";
+    case OP_CONV: return "conv_igemm";
+    case OP_MAXPOOL: return "maxpool";
+    case OP_HEAD1X1: return "head1x1";
+    default: return "upsample_argmax";
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbc_create(nbc_ctx** out, int hip_device) {
+  if (!out) return set_error(NBC_ERR_INVALID, "nbc_create: null out");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return set_error(NBC_ERR_HIP, std::string("nbc_create: no HIP device (") + hipGetErrorString(e) + ")");
+  if (hip_device < 0 || hip_device >= ndev) return set_error(NBC_ERR_INVALID, "nbc_create: bad device index");
+  NBC_HIP(hipSetDevice(hip_device));
+  hipDeviceProp_t prop;
+  NBC_HIP(hipGetDeviceProperties(&prop, hip_device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(NBC_ERR_HIP, std::string("nbc_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  nbc_ctx* c = new nbc_ctx();
+  c->device = hip_device;
+  *out = c;
+  return NBC_OK;
+}
+
+int nbc_destroy(nbc_ctx* c) {
+  if (!c) return NBC_OK;
+  (void)hipSetDevice(c->device);
+  for (void* b : c->bufs) if (b) (void)hipFree(b);
+  if (c->lowres) (void)hipFree(c->lowres);
+  if (c->owned_weights) (void)hipFree(c->owned_weights);
+  for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+  delete c;
+  return NBC_OK;
+}
+
+int nbc_attach_weights(nbc_ctx* c, const void* dev_blob, size_t bytes, int precision) {
+  if (!c || !dev_blob) return set_error(NBC_ERR_INVALID, "nbc_attach_weights: null argument");
+  if (precision != NBC_PREC_FP32 && precision != NBC_PREC_BF16)
+    return set_error(NBC_ERR_INVALID, "nbc_attach_weights: unknown precision");
+  PackedLayout L = packed_layout(precision);
+  if (bytes < L.total_bytes) return set_error(NBC_ERR_INVALID, "nbc_attach_weights: blob smaller than the packed layout");
+  if (reinterpret_cast<uintptr_t>(dev_blob) % 256 != 0)
+    return set_error(NBC_ERR_INVALID, "nbc_attach_weights: blob must be 256-byte aligned");
+  if (c->owned_weights && c->owned_weights != dev_blob) { (void)hipFree(c->owned_weights); c->owned_weights = nullptr; }
+  c->weights = static_cast<const unsigned char*>(dev_blob);
+  c->layout = L;
+  if (c->precision != precision) c->plan = Plan();   // element size changed: re-plan
+  c->precision = precision;
+  return NBC_OK;
+}
+
+int nbc_load_weights(nbc_ctx* c, const nbc_tensor* tensors, int n, int precision) {
+  if (!c) return set_error(NBC_ERR_INVALID, "nbc_load_weights: null context");
+  const size_t bytes = nbc_packed_weights_bytes(precision);
+  if (bytes == 0) return set_error(NBC_ERR_INVALID, "nbc_load_weights: unknown precision");
+  std::vector<unsigned char> host(bytes);
+  int rc = nbc_pack_weights(tensors, n, precision, host.data(), bytes);
+  if (rc != NBC_OK) return rc;
+  NBC_HIP(hipSetDevice(c->device));
+  void* dev = nullptr;
+  NBC_HIP(hipMalloc(&dev, bytes));
+  hipError_t e = hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(dev); return set_error(NBC_ERR_HIP, std::string("hipMemcpy(weights): ") + hipGetErrorString(e)); }
+  if (c->owned_weights) (void)hipFree(c->owned_weights);
+  c->owned_weights = nullptr;
+  rc = nbc_attach_weights(c, dev, bytes, precision);
+  if (rc != NBC_OK) { (void)hipFree(dev); return rc; }
+  c->owned_weights = dev;
+  return NBC_OK;
+}
+
+int nbc_set_normalization(nbc_ctx* c, const float mean[3], const float stdv[3]) {
+  if (!c || !mean || !stdv) return set_error(NBC_ERR_INVALID, "nbc_set_normalization: null argument");
+  for (int i = 0; i < 3; ++i) { c->mean[i] = mean[i]; c->stdv[i] = stdv[i]; }
+  return NBC_OK;
+}
+
+int nbc_set_keep_activations(nbc_ctx* c, int on) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  if (c->keep != (on != 0)) c->plan = Plan();
+  c->keep = on != 0;
+  return NBC_OK;
+}
+
+int nbc_set_profiling(nbc_ctx* c, int on) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  c->profiling = on != 0;
+  return NBC_OK;
+}
+
+int nbc_reserve(nbc_ctx* c, int N, int H, int W) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  if (c->precision < 0) return set_error(NBC_ERR_STATE, "nbc_reserve: no weights attached");
+  if (N < 1 || H < 8 || W < 8) return set_error(NBC_ERR_INVALID, "nbc_reserve: need N>=1, H>=8, W>=8");
+  NBC_HIP(hipSetDevice(c->device));
+  const Plan& P = c->plan;
+  if (P.N == N && P.H == H && P.W == W && P.precision == c->precision && P.keep == c->keep) return NBC_OK;
+  return build_plan(c, N, H, W);
+}
+
+int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
+                float* logits_lowres_dev, float* logits_full_dev, void* labels_dev, int labels_dtype,
+                int64_t* counts_dev, int exclude_nodes, void* hip_stream) {
+  if (!c || !x_dev) return set_error(NBC_ERR_INVALID, "nbc_forward: null argument");
+  if (!c->weights) return set_error(NBC_ERR_STATE, "nbc_forward: no weights attached (load_state_dict first)");
+  if (x_dtype != NBC_IN_F32_NCHW && x_dtype != NBC_IN_U8_NHWC) return set_error(NBC_ERR_INVALID, "nbc_forward: bad x_dtype");
+  if (labels_dtype != NBC_LABEL_U8 && labels_dtype != NBC_LABEL_I64) return set_error(NBC_ERR_INVALID, "nbc_forward: bad labels_dtype");
+  int rc = nbc_reserve(c, N, H, W);
+  if (rc != NBC_OK) return rc;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const Plan& P = c->plan;
+  const auto& units = conv_units();
+  const int prec = c->precision;
+
+  const size_t nops = P.ops.size();
+  if (c->profiling && c->events.size() < nops + 1) {
+    while (c->events.size() < nops + 1) {
+      hipEvent_t ev;
+      NBC_HIP(hipEventCreate(&ev));
+      c->events.push_back(ev);
+    }
+  }
+  float* lowres = logits_lowres_dev ? logits_lowres_dev : c->lowres;
+
+  if (c->profiling) NBC_HIP(hipEventRecord(c->events[0], s));
+  for (size_t i = 0; i < nops; ++i) {
+    const Op& o = P.ops[i];
+    hipError_t e = hipSuccess;
+    switch (o.kind) {
+      case OP_INGEST:
+        if (x_dtype == NBC_IN_F32_NCHW)
+          e = launch_ingest_f32(static_cast<const float*>(x_dev), c->bufs[o.out_buf], N, H, W, prec, s);
+        else
+          e = launch_ingest_u8(static_cast<const uint8_t*>(x_dev), c->bufs[o.out_buf], N, H, W, c->mean, c->stdv, prec, s);
+        break;
+      case OP_CONV: {
+        const ConvUnit& u = units[o.unit];
+        const PackedConv& pc = c->layout.convs[o.unit];
+        ConvArgs a{};
+        a.x = c->bufs[o.in_buf];
+        a.w = c->weights + pc.w_off;
+        a.scale = reinterpret_cast<const float*>(c->weights + pc.scale_off);
+        a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
+        a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
+        a.y = c->bufs[o.out_buf];
+        a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
+        a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
+        a.KH = u.k; a.KW = u.k; a.stride = u.stride; a.pad = u.pad; a.dil = u.dil;
+        a.M = N * o.Ho * o.Wo;
+        a.ksteps = pc.ksteps;
+        a.relu = u.relu ? 1 : 0;
+        a.stem = pc.stem ? 1 : 0;
+        if (o.Ci != pc.cin_pad) return set_error(NBC_ERR_STATE, "plan/channel mismatch at " + o.name);
+        e = launch_conv_igemm(a, prec, s);
+        break;
+      }
+      case OP_MAXPOOL:
+        e = launch_maxpool3x3s2(c->bufs[o.in_buf], c->bufs[o.out_buf], N, o.Hi, o.Wi, o.Ci, o.Ho, o.Wo, prec, s);
+        break;
+      case OP_HEAD1X1: {
+        const PackedConv& pc = c->layout.convs[o.unit];
+        if (o.Ci != 512) return set_error(NBC_ERR_STATE, "classifier.4 expects 512 input channels");
+        e = launch_head1x1(c->bufs[o.in_buf], reinterpret_cast<const float*>(c->weights + pc.w_off),
+                           reinterpret_cast<const float*>(c->weights + pc.shift_off), lowres, N, o.Ho * o.Wo, prec, s);
+        break;
+      }
+      case OP_UPSAMPLE:
+        if (counts_dev) {
+          e = hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * 3 * N, s);
+          if (e != hipSuccess) break;
+        }
+        if (logits_full_dev || labels_dev || counts_dev)
+          e = launch_upsample_argmax(lowres, N, P.h, P.w, H, W, logits_full_dev, labels_dev,
+                                     labels_dtype == NBC_LABEL_I64 ? 1 : 0,
+                                     reinterpret_cast<unsigned long long*>(counts_dev), exclude_nodes, s);
+        break;
+    }
+    if (e != hipSuccess)
+      return set_error(NBC_ERR_HIP, "launch of " + o.name + " failed: " + hipGetErrorString(e));
+    if (c->profiling) NBC_HIP(hipEventRecord(c->events[i + 1], s));
+  }
+
+  if (c->profiling) {
+    NBC_HIP(hipEventSynchronize(c->events[nops]));
+    c->records.assign(nops, nbc_op_record{});
+    for (size_t i = 0; i < nops; ++i) {
+      const Op& o = P.ops[i];
+      nbc_op_record& r = c->records[i];
+      std::snprintf(r.name, sizeof(r.name), "%s", o.name.c_str());
+      std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel_name(o.kind));
+      NBC_HIP(hipEventElapsedTime(&r.ms, c->events[i], c->events[i + 1]));
+      r.flops = o.flops;
+      r.bytes = o.bytes;
+      r.kh = r.kw = (o.kind == OP_CONV || o.kind == OP_HEAD1X1) ? units[o.unit].k : 0;
+    }
+  }
+  return NBC_OK;
+}
+
+int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, int H, int W,
+                        float* logits_full_dev, void* labels_dev, int labels_dtype,
+                        int64_t* counts_dev, int exclude_nodes, void* hip_stream) {
+  if (!c || !lowres) return set_error(NBC_ERR_INVALID, "nbc_upsample_argmax: null argument");
+  if (N < 1 || h < 1 || w < 1 || H < 1 || W < 1) return set_error(NBC_ERR_INVALID, "nbc_upsample_argmax: bad shape");
+  if (labels_dtype != NBC_LABEL_U8 && labels_dtype != NBC_LABEL_I64) return set_error(NBC_ERR_INVALID, "nbc_upsample_argmax: bad labels_dtype");
+  NBC_HIP(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  if (counts_dev) NBC_HIP(hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * 3 * N, s));
+  NBC_HIP(launch_upsample_argmax(lowres, N, h, w, H, W, logits_full_dev, labels_dev,
+                                 labels_dtype == NBC_LABEL_I64 ? 1 : 0,
+                                 reinterpret_cast<unsigned long long*>(counts_dev), exclude_nodes, s));
+  return NBC_OK;
+}
+
+int nbc_num_op_records(nbc_ctx* c) { return c ? (int)c->records.size() : 0; }
+
+int nbc_get_op_record(nbc_ctx* c, int index, nbc_op_record* out) {
+  if (!c || !out || index < 0 || index >= (int)c->records.size())
+    return set_error(NBC_ERR_INVALID, "nbc_get_op_record: bad index");
+  *out = c->records[index];
+  return NBC_OK;
+}
+
+int nbc_read_activation(nbc_ctx* c, const char* name, float* dst_host, size_t capacity, int64_t shape[4]) {
+  if (!c || !name || !dst_host) return set_error(NBC_ERR_INVALID, "nbc_read_activation: null argument");
+  if (!c->plan.keep) return set_error(NBC_ERR_STATE, "nbc_read_activation: keep-activations is off");
+  auto it = c->act_of.find(name);
+  if (it == c->act_of.end()) return set_error(NBC_ERR_INVALID, std::string("nbc_read_activation: unknown op ") + name);
+  const Op& o = c->plan.ops[it->second];
+  if (o.out_buf < 0) return set_error(NBC_ERR_INVALID, "nbc_read_activation: op has no activation buffer");
+  const int N = c->plan.N;
+  const size_t elems = (size_t)N * o.Ho * o.Wo * o.Co;
+  if (capacity < elems) return set_error(NBC_ERR_INVALID, "nbc_read_activation: destination too small");
+  NBC_HIP(hipSetDevice(c->device));
+  float* tmp = nullptr;
+  NBC_HIP(hipMalloc((void**)&tmp, elems * sizeof(float)));
+  hipError_t e = launch_nhwc_to_nchw_f32(c->bufs[o.out_buf], tmp, N, o.Ho, o.Wo, o.Co, c->precision, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(dst_host, tmp, elems * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) return set_error(NBC_ERR_HIP, std::string("nbc_read_activation: ") + hipGetErrorString(e));
+  if (shape) { shape[0] = N; shape[1] = o.Co; shape[2] = o.Ho; shape[3] = o.Wo; }
+  return NBC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// Launchers of the gfx950 kernels (definitions in conv_igemm.hip and pointwise.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace nbc {
+
+// Implicit-GEMM convolution on NHWC activations, fused  y = relu?(acc*scale + shift (+ res)).
+// GEMM view: rows m = (image, oy, ox), columns n = cout, K = (kh, kw, ci) in 128-byte K-steps.
+struct ConvArgs {
+  const void* x;        // [N][Hi][Wi][Ci] elements
+  const void* w;        // [Co][ksteps*128 bytes]
+  const float* scale;   // [Co]
+  const float* shift;   // [Co]
+  const void* res;      // nullable, [M][Co] elements (the identity of a bottleneck)
+  void* y;              // [M][Co] elements
+  int N, Hi, Wi, Ci;
+  int Ho, Wo, Co;
+  int KH, KW, stride, pad, dil;
+  int M;                // N*Ho*Wo
+  int ksteps;
+  int relu;
+  int stem;             // one 16-byte chunk per tap (Ci*elem == 16 bytes)
+};
+
+// precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_32x32x16_bf16)
+hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
+
+// float32 NCHW [N,3,H,W] -> NHWC elements padded to 16 bytes per pixel.
+hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int precision, hipStream_t s);
+// uint8 NHWC [N,H,W,3] -> same, applying (u8/255 - mean)/std in f32 (dataset.py:175-186).
+hipError_t launch_ingest_u8(const uint8_t* x, void* y, int N, int H, int W, const float mean[3],
+                            const float stdv[3], int precision, hipStream_t s);
+// MaxPool2d(3, stride 2, padding 1) on NHWC, C a multiple of the 16-byte chunk.
+hipError_t launch_maxpool3x3s2(const void* x, void* y, int N, int Hi, int Wi, int C, int Ho, int Wo,
+                               int precision, hipStream_t s);
+// classifier.4: 1x1 conv 512 -> 3 with bias; f32 weights [3][512]; output f32 NCHW [N,3,h,w].
+hipError_t launch_head1x1(const void* x, const float* w, const float* bias, float* y, int N, int hw,
+                          int precision, hipStream_t s);
+// Bicubic (A=-0.75, align_corners=False) upsample of f32 NCHW [N,3,h,w] to HxW, fused with the
+// per-pixel argmax, the optional 2->1 remap and the per-class pixel counts.
+hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int H, int W,
+                                  float* logits_full, void* labels, int labels_i64,
+                                  unsigned long long* counts, int exclude_nodes, hipStream_t s);
+// NHWC elements -> float32 NCHW (debug read-back of activations).
+hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W, int C, int precision,
+                                   hipStream_t s);
+
+}  // namespace nbc

@@ -1,0 +1,274 @@
+// Host-only part of libnbc_hip.so: topology tables, state_dict checking and weight packing.
+// No HIP calls in this file (it is also what the CPU-only tests exercise).
+#include "nbc_net.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+
+#include "../../include/nbc.h"
+#include "nbc_internal.hpp"
+
+namespace nbc {
+
+static std::vector<ConvUnit> build_units() {
+  std::vector<ConvUnit> u;
+  u.push_back({"backbone.conv1", "backbone.bn1", 3, 64, 7, 2, 3, 1, true, false, false, 0});
+  int inplanes = 64, dilation = 1;
+  const int planes_[4] = {64, 128, 256, 512};
+  const int blocks_[4] = {3, 4, 6, 3};
+  const int stride_[4] = {1, 2, 2, 2};
+  const bool dilate_[4] = {false, false, true, true};
+  for (int li = 0; li < 4; ++li) {
+    int planes = planes_[li], stride = stride_[li];
+    int prev_dil = dilation;
+    if (dilate_[li]) { dilation *= stride; stride = 1; }
+    for (int bi = 0; bi < blocks_[li]; ++bi) {
+      std::string p = "backbone.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+      int s = bi == 0 ? stride : 1;
+      int d = bi == 0 ? prev_dil : dilation;
+      u.push_back({p + ".conv1", p + ".bn1", inplanes, planes, 1, 1, 0, 1, true, false, false, 1});
+      u.push_back({p + ".conv2", p + ".bn2", planes, planes, 3, s, d, d, true, false, false, 0});
+      if (bi == 0)
+        u.push_back({p + ".downsample.0", p + ".downsample.1", inplanes, planes * 4, 1, s, 0, 1,
+                     false, false, false, 0});
+      u.push_back({p + ".conv3", p + ".bn3", planes, planes * 4, 1, 1, 0, 1, true, false, true, 0});
+      inplanes = planes * 4;
+    }
+  }
+  u.push_back({"classifier.0", "classifier.1", 2048, 512, 3, 1, 1, 1, true, false, false, 0});
+  u.push_back({"classifier.4", "", 512, kNumClasses, 1, 1, 0, 1, false, true, false, 0});
+  return u;
+}
+
+const std::vector<ConvUnit>& conv_units() {
+  static const std::vector<ConvUnit> u = build_units();
+  return u;
+}
+
+static std::vector<StateKey> build_keys() {
+  // nn.Module.state_dict() order: inside a Bottleneck conv1,bn1,conv2,bn2,conv3,bn3,downsample.
+  std::vector<StateKey> keys;
+  const auto& units = conv_units();
+  std::vector<const ConvUnit*> ordered;
+  for (size_t i = 0; i < units.size(); ++i) {
+    const ConvUnit& c = units[i];
+    if (c.name.size() > 13 && c.name.compare(c.name.size() - 13, 13, ".downsample.0") == 0) continue;
+    ordered.push_back(&c);
+    if (c.residual && i >= 1) {
+      const ConvUnit& prev = units[i - 1];
+      if (prev.name.size() > 13 && prev.name.compare(prev.name.size() - 13, 13, ".downsample.0") == 0)
+        ordered.push_back(&prev);
+    }
+  }
+  auto add = [&](const std::string& n, std::initializer_list<int64_t> shp, int dtype) {
+    StateKey k;
+    k.name = n;
+    k.ndim = (int)shp.size();
+    k.dtype = dtype;
+    int i = 0;
+    for (int j = 0; j < 4; ++j) k.shape[j] = 1;
+    for (int64_t s : shp) k.shape[i++] = s;
+    keys.push_back(k);
+  };
+  for (const ConvUnit* c : ordered) {
+    add(c->name + ".weight", {c->cout, c->cin, c->k, c->k}, 0);
+    if (c->bias) add(c->name + ".bias", {c->cout}, 0);
+    if (!c->bn.empty()) {
+      add(c->bn + ".weight", {c->cout}, 0);
+      add(c->bn + ".bias", {c->cout}, 0);
+      add(c->bn + ".running_mean", {c->cout}, 0);
+      add(c->bn + ".running_var", {c->cout}, 0);
+      add(c->bn + ".num_batches_tracked", {}, 1);
+    }
+  }
+  return keys;
+}
+
+const std::vector<StateKey>& state_keys() {
+  static const std::vector<StateKey> k = build_keys();
+  return k;
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+PackedLayout packed_layout(int precision) {
+  PackedLayout L;
+  const int eb = elem_bytes(precision);
+  size_t off = 0;
+  for (const ConvUnit& c : conv_units()) {
+    PackedConv p{};
+    p.stem = (c.cin == 3);
+    p.head = c.bn.empty();
+    if (p.head) {                      // f32 [3][512] + bias
+      p.cin_pad = c.cin;
+      p.ksteps = 0;
+      p.w_off = off;
+      off = align_up(off + (size_t)c.cout * c.cin * 4, 256);
+      p.scale_off = off;               // unused
+      p.shift_off = off;               // bias
+      off = align_up(off + (size_t)c.cout * 4, 256);
+    } else {
+      if (p.stem) {
+        p.cin_pad = kChunkBytes / eb;
+        p.ksteps = (c.k * c.k + 7) / 8;
+      } else {
+        p.cin_pad = c.cin;
+        p.ksteps = c.k * c.k * c.cin * eb / kKStepBytes;
+      }
+      p.w_off = off;
+      off = align_up(off + (size_t)c.cout * p.ksteps * kKStepBytes, 256);
+      p.scale_off = off;
+      off = align_up(off + (size_t)c.cout * 4, 256);
+      p.shift_off = off;
+      off = align_up(off + (size_t)c.cout * 4, 256);
+    }
+    L.convs.push_back(p);
+  }
+  L.total_bytes = off;
+  return L;
+}
+
+uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);  // keep NaN a NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                               // RNE
+  return (uint16_t)(u >> 16);
+}
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+}  // namespace nbc
+
+using namespace nbc;
+
+extern "C" {
+
+const char* nbc_last_error(void) { return g_last_error.c_str(); }
+const char* nbc_version(void) { return "nbc-hip 0.1 (gfx950)"; }
+
+int nbc_num_convs(void) { return (int)conv_units().size(); }
+
+int nbc_conv_info(int index, nbc_conv_desc* out) {
+  const auto& u = conv_units();
+  if (!out || index < 0 || index >= (int)u.size()) return set_error(NBC_ERR_INVALID, "nbc_conv_info: bad index");
+  const ConvUnit& c = u[index];
+  std::memset(out, 0, sizeof(*out));
+  std::snprintf(out->name, sizeof(out->name), "%s", c.name.c_str());
+  std::snprintf(out->bn, sizeof(out->bn), "%s", c.bn.c_str());
+  out->cin = c.cin; out->cout = c.cout; out->k = c.k; out->stride = c.stride;
+  out->pad = c.pad; out->dil = c.dil;
+  out->relu = c.relu; out->bias = c.bias; out->residual = c.residual;
+  return NBC_OK;
+}
+
+int nbc_num_state_keys(void) { return (int)state_keys().size(); }
+
+int nbc_state_key(int index, const char** name, int64_t shape[4], int32_t* ndim, int32_t* dtype) {
+  const auto& k = state_keys();
+  if (index < 0 || index >= (int)k.size()) return set_error(NBC_ERR_INVALID, "nbc_state_key: bad index");
+  if (name) *name = k[index].name.c_str();
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = k[index].shape[i];
+  if (ndim) *ndim = k[index].ndim;
+  if (dtype) *dtype = k[index].dtype;
+  return NBC_OK;
+}
+
+int nbc_lowres_size(int H, int W, int* h, int* w) {
+  if (H < 1 || W < 1) return set_error(NBC_ERR_INVALID, "nbc_lowres_size: H,W must be >= 1");
+  for (int i = 0; i < 3; ++i) { H = (H - 1) / 2 + 1; W = (W - 1) / 2 + 1; }
+  if (h) *h = H;
+  if (w) *w = W;
+  return NBC_OK;
+}
+
+size_t nbc_packed_weights_bytes(int precision) {
+  if (precision != NBC_PREC_FP32 && precision != NBC_PREC_BF16) return 0;
+  return packed_layout(precision).total_bytes;
+}
+
+int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob, size_t blob_bytes) {
+  if (precision != NBC_PREC_FP32 && precision != NBC_PREC_BF16)
+    return set_error(NBC_ERR_INVALID, "nbc_pack_weights: unknown precision");
+  if (!tensors || n < 0 || !blob) return set_error(NBC_ERR_INVALID, "nbc_pack_weights: null argument");
+  const PackedLayout L = packed_layout(precision);
+  if (blob_bytes < L.total_bytes) return set_error(NBC_ERR_INVALID, "nbc_pack_weights: blob too small");
+
+  // --- strict key / shape check, in the manner of nn.Module.load_state_dict (models.py:222)
+  std::map<std::string, const nbc_tensor*> given;
+  std::string unexpected, missing, badshape;
+  std::set<std::string> expected;
+  for (const StateKey& k : state_keys()) expected.insert(k.name);
+  for (int i = 0; i < n; ++i) {
+    if (!tensors[i].name) return set_error(NBC_ERR_INVALID, "nbc_pack_weights: tensor without a name");
+    if (!expected.count(tensors[i].name)) unexpected += std::string(" \"") + tensors[i].name + "\"";
+    given[tensors[i].name] = &tensors[i];
+  }
+  for (const StateKey& k : state_keys()) {
+    auto it = given.find(k.name);
+    if (it == given.end()) { missing += " \"" + k.name + "\""; continue; }
+    const nbc_tensor* t = it->second;
+    bool ok = (t->ndim == k.ndim) && t->dtype == k.dtype && (t->data != nullptr);
+    for (int j = 0; ok && j < k.ndim; ++j) ok = (t->shape[j] == k.shape[j]);
+    if (!ok) badshape += " \"" + k.name + "\"";
+  }
+  if (!missing.empty() || !unexpected.empty() || !badshape.empty()) {
+    std::string msg = "Error(s) in loading state_dict for fcn_resnet50:";
+    if (!missing.empty()) msg += " Missing key(s) in state_dict:" + missing + ".";
+    if (!unexpected.empty()) msg += " Unexpected key(s) in state_dict:" + unexpected + ".";
+    if (!badshape.empty()) msg += " size or dtype mismatch for:" + badshape + ".";
+    return set_error(NBC_ERR_KEYS, msg);
+  }
+
+  std::memset(blob, 0, L.total_bytes);
+  unsigned char* base = static_cast<unsigned char*>(blob);
+  const int eb = elem_bytes(precision);
+  const auto& units = conv_units();
+  for (size_t ui = 0; ui < units.size(); ++ui) {
+    const ConvUnit& c = units[ui];
+    const PackedConv& p = L.convs[ui];
+    const float* w = static_cast<const float*>(given[c.name + ".weight"]->data);
+    if (p.head) {
+      std::memcpy(base + p.w_off, w, (size_t)c.cout * c.cin * 4);
+      std::memcpy(base + p.shift_off, given[c.name + ".bias"]->data, (size_t)c.cout * 4);
+      continue;
+    }
+    const size_t row_bytes = (size_t)p.ksteps * kKStepBytes;
+    for (int o = 0; o < c.cout; ++o) {
+      unsigned char* row = base + p.w_off + (size_t)o * row_bytes;
+      for (int kh = 0; kh < c.k; ++kh)
+        for (int kw = 0; kw < c.k; ++kw)
+          for (int ci = 0; ci < c.cin; ++ci) {
+            const float v = w[(((size_t)o * c.cin + ci) * c.k + kh) * c.k + kw];
+            const size_t kidx = (size_t)(kh * c.k + kw) * p.cin_pad + ci;
+            if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;
+            else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
+          }
+    }
+    // eval-mode BatchNorm as ATen applies it: alpha = gamma * invstd, beta = bias - mean * alpha
+    const float* g = static_cast<const float*>(given[c.bn + ".weight"]->data);
+    const float* b = static_cast<const float*>(given[c.bn + ".bias"]->data);
+    const float* mu = static_cast<const float*>(given[c.bn + ".running_mean"]->data);
+    const float* var = static_cast<const float*>(given[c.bn + ".running_var"]->data);
+    float* scale = reinterpret_cast<float*>(base + p.scale_off);
+    float* shift = reinterpret_cast<float*>(base + p.shift_off);
+    for (int o = 0; o < c.cout; ++o) {
+      const float invstd = 1.0f / std::sqrt(var[o] + kBnEps);
+      const float alpha = g[o] * invstd;
+      const float t = mu[o] * alpha;
+      scale[o] = alpha;
+      shift[o] = b[o] - t;
+    }
+  }
+  return NBC_OK;
+}
+
+}  // extern "C"

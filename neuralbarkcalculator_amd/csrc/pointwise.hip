@@ -1,0 +1,355 @@
+// Memory-bound kernels of the path: image ingest, max-pool, the 1x1 classifier and the fused
+// bicubic-upsample + argmax + class-count kernel.  All are HBM/L2-bound byte movers: 16-byte
+// lane accesses, no MFMA.
+#include "nbc_kernels.hpp"
+
+namespace nbc {
+namespace {
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// One pixel's three normalised channels -> one 16-byte NHWC pixel (f32x4 or bf16x8, zero padded).
+template <int PREC>
+__device__ __forceinline__ void store_pixel(void* y, size_t pix, float c0, float c1, float c2) {
+  if constexpr (PREC == 0) {
+    reinterpret_cast<float4*>(y)[pix] = make_float4(c0, c1, c2, 0.f);
+  } else {
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16_bits(c0) | ((unsigned)f32_to_bf16_bits(c1) << 16);
+    o.y = (unsigned)f32_to_bf16_bits(c2);
+    o.z = 0; o.w = 0;
+    reinterpret_cast<uint4*>(y)[pix] = o;
+  }
+}
+
+// `batch[0].to(device)` of models.py:269: float32 NCHW in, NHWC out.
+template <int PREC>
+__global__ void ingest_f32_kernel(const float* __restrict__ x, void* __restrict__ y, int N, int HW) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t img = i / HW, pix = i - img * HW;
+    const float* xp = x + img * 3 * (size_t)HW + pix;
+    store_pixel<PREC>(y, i, xp[0], xp[(size_t)HW], xp[2 * (size_t)HW]);
+  }
+}
+
+// ToTensor (u8 / 255) then Normalize ((x - mean) / std), dataset.py:175-186, in IEEE f32.
+template <int PREC>
+__global__ void ingest_u8_kernel(const uint8_t* __restrict__ x, void* __restrict__ y, size_t total,
+                                 float m0, float m1, float m2, float s0, float s1, float s2) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const uint8_t* xp = x + 3 * i;
+    const float a = __fdiv_rn((float)xp[0], 255.0f);
+    const float b = __fdiv_rn((float)xp[1], 255.0f);
+    const float c = __fdiv_rn((float)xp[2], 255.0f);
+    store_pixel<PREC>(y, i, __fdiv_rn(__fsub_rn(a, m0), s0), __fdiv_rn(__fsub_rn(b, m1), s1),
+                      __fdiv_rn(__fsub_rn(c, m2), s2));
+  }
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1): padding is -inf, i.e. out-of-range taps are skipped;
+// NaN propagates like ATen's max_pool2d (a NaN tap wins).
+template <int PREC>
+__global__ void maxpool_kernel(const void* __restrict__ x, void* __restrict__ y, int N, int Hi, int Wi,
+                               int C, int Ho, int Wo) {
+  constexpr int EPC = PREC == 0 ? 4 : 8;          // elements per 16-byte chunk
+  const int chunks = C / EPC;
+  const size_t total = (size_t)N * Ho * Wo * chunks;
+  const uint4* xv = static_cast<const uint4*>(x);
+  uint4* yv = static_cast<uint4*>(y);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % chunks);
+    size_t pix = i / chunks;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int img = (int)(pix / Ho);
+    float best[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) best[e] = -__builtin_inff();
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)Hi) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)Wi) continue;
+        const uint4 v = xv[((size_t)(img * Hi + iy) * Wi + ix) * chunks + ch];
+        float f[EPC];
+        if constexpr (PREC == 0) {
+          f[0] = __builtin_bit_cast(float, v.x); f[1] = __builtin_bit_cast(float, v.y);
+          f[2] = __builtin_bit_cast(float, v.z); f[3] = __builtin_bit_cast(float, v.w);
+        } else {
+          const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f[2 * q] = __builtin_bit_cast(float, u[q] << 16);
+            f[2 * q + 1] = __builtin_bit_cast(float, u[q] & 0xffff0000u);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (f[e] > best[e] || f[e] != f[e]) best[e] = f[e];
+      }
+    }
+    uint4 o;
+    if constexpr (PREC == 0) {
+      o.x = __builtin_bit_cast(unsigned, best[0]); o.y = __builtin_bit_cast(unsigned, best[1]);
+      o.z = __builtin_bit_cast(unsigned, best[2]); o.w = __builtin_bit_cast(unsigned, best[3]);
+    } else {          // inputs were bf16, so the max is exactly representable: truncate
+      unsigned u[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        u[q] = (__builtin_bit_cast(unsigned, best[2 * q]) >> 16) |
+               (__builtin_bit_cast(unsigned, best[2 * q + 1]) & 0xffff0000u);
+      o = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+    yv[i] = o;
+  }
+}
+
+// classifier.4 (models.py:121): 1x1 conv 512 -> 3 with bias.  One wave per pixel: lane l owns
+// channels 8l..8l+7 (an f32 fma chain in channel order), then a 64-lane xor-tree.
+template <int PREC>
+__global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x,
+                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ y, int M, int hw) {
+  constexpr int CIN = 512;
+  constexpr int PIX_PER_WAVE = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float wr[3][8];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wr[c][e] = w[c * CIN + lane * 8 + e];
+  const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+  const int first = (blockIdx.x * 4 + wave) * PIX_PER_WAVE;
+  for (int q = 0; q < PIX_PER_WAVE; ++q) {
+    const int m = first + q;
+    if (m >= M) break;                                   // wave-uniform
+    float f[8];
+    if constexpr (PREC == 0) {
+      const float4* xp = reinterpret_cast<const float4*>(static_cast<const float*>(x) + (size_t)m * CIN + lane * 8);
+      const float4 a = xp[0], b = xp[1];
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+      const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(x) + (size_t)m * CIN + lane * 8);
+      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f[2 * k] = __builtin_bit_cast(float, u[k] << 16);
+        f[2 * k + 1] = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+      }
+    }
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s[c] = __builtin_fmaf(f[e], wr[c][e], s[c]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) s[c] += __shfl_xor(s[c], off, 64);
+    if (lane == 0) {
+      const int img = m / hw, pix = m - img * hw;
+      float* yp = y + (size_t)img * 3 * hw + pix;
+      yp[0] = s[0] + b0;
+      yp[(size_t)hw] = s[1] + b1;
+      yp[2 * (size_t)hw] = s[2] + b2;
+    }
+  }
+}
+
+// Cubic-convolution taps, A = -0.75, exactly the expressions of ATen's
+// get_cubic_upsample_coefficients (f32).
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+  const float A = -0.75f;
+  const float x1 = t;
+  c[0] = ((A * (x1 + 1.0f) - 5.0f * A) * (x1 + 1.0f) + 8.0f * A) * (x1 + 1.0f) - 4.0f * A;
+  c[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+  const float x2 = 1.0f - t;
+  c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  c[3] = ((A * (x2 + 1.0f) - 5.0f * A) * (x2 + 1.0f) + 8.0f * A) * (x2 + 1.0f) - 4.0f * A;
+}
+
+// Source position for output index o: s = scale*(o+0.5)-0.5 (not clamped below 0 for cubic);
+// i0 = floor(s) capped at in-1; t = clamp(s - i0, 0, 1); taps i0-1..i0+2 clamped to [0,in-1]
+// (ATen area_pixel_compute_source_index + guard_index_and_lambda + upsample_get_value_bounded).
+__device__ __forceinline__ void cubic_setup(int o, float scale, int in, int idx[4], float c[4]) {
+  const float s = scale * ((float)o + 0.5f) - 0.5f;
+  int i0 = (int)floorf(s);
+  if (i0 > in - 1) i0 = in - 1;
+  float t = s - (float)i0;
+  t = fminf(fmaxf(t, 0.f), 1.f);
+  cubic_coeffs(t, c);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = i0 - 1 + k;
+    idx[k] = i < 0 ? 0 : (i > in - 1 ? in - 1 : i);
+  }
+}
+
+// models.py:38-41 (bicubic to the input size) + models.py:270 (argmax over the 3 classes) +
+// models.py:273-276 (optional 2 -> 1) + the counting of models.py:324-331.
+// grid = (ceil(W/256), H, N), one output pixel per thread.
+__global__ __launch_bounds__(256) void upsample_argmax_kernel(
+    const float* __restrict__ lowres, int h, int w, int H, int W, float scale_y, float scale_x,
+    float* __restrict__ logits_full, void* __restrict__ labels, int labels_i64,
+    unsigned long long* __restrict__ counts, int exclude_nodes) {
+  __shared__ unsigned int blk_counts[3];
+  if (threadIdx.x < 3) blk_counts[threadIdx.x] = 0;
+  __syncthreads();
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  const int oy = blockIdx.y;
+  const int img = blockIdx.z;
+  const bool live = ox < W;
+  int label = -1;
+  if (live) {
+    int iy[4], ix[4];
+    float cy[4], cx[4];
+    cubic_setup(oy, scale_y, h, iy, cy);
+    cubic_setup(ox, scale_x, w, ix, cx);
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float* src = lowres + ((size_t)img * 3 + c) * h * w;
+      float out = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* row = src + (size_t)iy[j] * w;
+        float t = row[ix[0]] * cx[0];
+        t = __builtin_fmaf(row[ix[1]], cx[1], t);
+        t = __builtin_fmaf(row[ix[2]], cx[2], t);
+        t = __builtin_fmaf(row[ix[3]], cx[3], t);
+        out = (j == 0) ? t * cy[0] : __builtin_fmaf(t, cy[j], out);
+      }
+      v[c] = out;
+      if (logits_full) logits_full[(((size_t)img * 3 + c) * H + oy) * W + ox] = out;
+    }
+    // torch.argmax: first maximum wins, NaN counts as the maximum.
+    int best = 0;
+    float bv = v[0];
+#pragma unroll
+    for (int c = 1; c < 3; ++c) {
+      const bool take = (v[c] > bv) || (v[c] != v[c] && bv == bv);
+      if (take) { best = c; bv = v[c]; }
+    }
+    if (exclude_nodes && best == 2) best = 1;
+    label = best;
+    if (labels) {
+      const size_t o = ((size_t)img * H + oy) * W + ox;
+      if (labels_i64) static_cast<long long*>(labels)[o] = best;
+      else static_cast<unsigned char*>(labels)[o] = (unsigned char)best;
+    }
+  }
+  if (counts) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const unsigned long long mask = __ballot(label == c);
+      if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&blk_counts[c], (unsigned)__popcll(mask));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && blk_counts[threadIdx.x])
+      atomicAdd(&counts[(size_t)img * 3 + threadIdx.x], (unsigned long long)blk_counts[threadIdx.x]);
+  }
+}
+
+template <int PREC>
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+  const size_t total = (size_t)N * HW * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t pix = i / C;                 // img*HW + p
+    const size_t img = pix / HW, p = pix - img * HW;
+    float v;
+    if constexpr (PREC == 0) v = static_cast<const float*>(x)[i];
+    else v = bf16_bits_to_f32(static_cast<const unsigned short*>(x)[i]);
+    y[(img * C + c) * (size_t)HW + p] = v;
+  }
+}
+
+inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  const size_t cap = 256 * 8;                 // 8 blocks per CU, grid-stride the rest
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int precision, hipStream_t s) {
+  const size_t total = (size_t)N * H * W;
+  const int g = grid_for(total, 256);
+  if (precision == 0) hipLaunchKernelGGL(ingest_f32_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, H * W);
+  else hipLaunchKernelGGL(ingest_f32_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, H * W);
+  return hipGetLastError();
+}
+
+hipError_t launch_ingest_u8(const uint8_t* x, void* y, int N, int H, int W, const float mean[3],
+                            const float stdv[3], int precision, hipStream_t s) {
+  const size_t total = (size_t)N * H * W;
+  const int g = grid_for(total, 256);
+  if (precision == 0)
+    hipLaunchKernelGGL(ingest_u8_kernel<0>, dim3(g), dim3(256), 0, s, x, y, total, mean[0], mean[1],
+                       mean[2], stdv[0], stdv[1], stdv[2]);
+  else
+    hipLaunchKernelGGL(ingest_u8_kernel<1>, dim3(g), dim3(256), 0, s, x, y, total, mean[0], mean[1],
+                       mean[2], stdv[0], stdv[1], stdv[2]);
+  return hipGetLastError();
+}
+
+hipError_t launch_maxpool3x3s2(const void* x, void* y, int N, int Hi, int Wi, int C, int Ho, int Wo,
+                               int precision, hipStream_t s) {
+  const int epc = precision == 0 ? 4 : 8;
+  if (C % epc != 0) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * Ho * Wo * (C / epc);
+  const int g = grid_for(total, 256);
+  if (precision == 0) hipLaunchKernelGGL(maxpool_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, Hi, Wi, C, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, Hi, Wi, C, Ho, Wo);
+  return hipGetLastError();
+}
+
+hipError_t launch_head1x1(const void* x, const float* w, const float* bias, float* y, int N, int hw,
+                          int precision, hipStream_t s) {
+  const int M = N * hw;
+  const int blocks = (M + 31) / 32;           // 4 waves x 8 pixels
+  if (precision == 0) hipLaunchKernelGGL(head1x1_kernel<0>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw);
+  else hipLaunchKernelGGL(head1x1_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw);
+  return hipGetLastError();
+}
+
+hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int H, int W,
+                                  float* logits_full, void* labels, int labels_i64,
+                                  unsigned long long* counts, int exclude_nodes, hipStream_t s) {
+  if (H > 65535 || N > 65535) return hipErrorInvalidValue;
+  // ATen area_pixel_compute_scale<float>(in, out, align_corners=false, scales=nullopt)
+  const float scale_y = (float)h / (float)H;
+  const float scale_x = (float)w / (float)W;
+  dim3 grid((W + 255) / 256, H, N);
+  hipLaunchKernelGGL(upsample_argmax_kernel, grid, dim3(256), 0, s, lowres, h, w, H, W, scale_y, scale_x,
+                     logits_full, labels, labels_i64, counts, exclude_nodes);
+  return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W, int C, int precision,
+                                   hipStream_t s) {
+  const size_t total = (size_t)N * H * W * C;
+  const int g = grid_for(total, 256);
+  if (precision == 0) hipLaunchKernelGGL(nhwc_to_nchw_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
+  return hipGetLastError();
+}
+
+}  // namespace nbc

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libnbc_hip.so, built in-tree if a source is newer (hipcc cross-compiles without a GPU)."""
+    from neuralbarkcalculator_amd import build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def sd_np():
+    """Synthetic 'trained-like' state_dict (numpy), seed 7: the weights of every golden."""
+    from neuralbarkcalculator_amd import synth
+    return synth.make_state_dict("trained_like", seed=7)
+
+
+@pytest.fixture(scope="session")
+def oracle_model(sd_np):
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50
+    torch.set_num_threads(os.cpu_count() or 1)
+    m = OracleFCNResNet50()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return m
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def load_golden_labels(name, b=0):
+    from PIL import Image
+    a = np.asarray(Image.open(os.path.join(GOLDEN, f"{name}_labels{b}.png")))
+    out = np.zeros(a.shape, dtype=np.uint8)
+    out[a == 127] = 1
+    out[a == 255] = 2
+    assert ((a == 0) | (a == 127) | (a == 255)).all()
+    return out

@@ -1,0 +1,157 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/nbc.h declares, describes the same network as the oracle, and packs a state_dict the
+way the kernels expect.  No compute call is made (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from neuralbarkcalculator_amd import _lib, topology
+from neuralbarkcalculator_amd.model import FCNResNet50, pack_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nbc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(built_lib, s), f"libnbc_hip.so does not export {s}"
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes signature table and nbc.h disagree"
+    assert b"gfx950" in built_lib.nbc_version()
+
+
+def test_topology_through_the_abi(built_lib):
+    units = topology.conv_units()
+    assert built_lib.nbc_num_convs() == len(units) == 55
+    d = _lib.NbcConvDesc()
+    for i, u in enumerate(units):
+        assert built_lib.nbc_conv_info(i, C.byref(d)) == 0
+        got = (d.name.decode(), d.bn.decode() or None, d.cin, d.cout, d.k, d.stride, d.pad, d.dil,
+               bool(d.relu), bool(d.bias), bool(d.residual))
+        want = (u.name, u.bn, u.cin, u.cout, u.k, u.stride, u.pad, u.dil, u.relu, u.bias, u.residual)
+        assert got == want
+    assert built_lib.nbc_conv_info(99, C.byref(d)) == _lib.NBC_ERR_INVALID
+    assert b"bad index" in built_lib.nbc_last_error()
+
+
+def test_state_keys_match_oracle(built_lib):
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50
+    sd = OracleFCNResNet50().state_dict()
+    n = built_lib.nbc_num_state_keys()
+    assert n == 326
+    name = C.c_char_p()
+    shape = (C.c_int64 * 4)()
+    ndim, dtype = C.c_int32(), C.c_int32()
+    keys = []
+    for i in range(n):
+        assert built_lib.nbc_state_key(i, C.byref(name), C.byref(shape), C.byref(ndim), C.byref(dtype)) == 0
+        k = name.value.decode()
+        keys.append(k)
+        assert tuple(shape[: ndim.value]) == tuple(sd[k].shape), k
+        assert dtype.value == (1 if sd[k].dtype == torch.int64 else 0)
+    assert keys == list(sd.keys())
+
+
+def test_lowres_size(built_lib):
+    h, w = C.c_int(), C.c_int()
+    for H, W in [(1024, 1024), (520, 1024), (203, 1024), (8, 8), (9, 17)]:
+        assert built_lib.nbc_lowres_size(H, W, C.byref(h), C.byref(w)) == 0
+        assert (h.value, w.value) == topology.out_hw(H, W)
+
+
+def test_strict_key_check_like_load_state_dict(built_lib, sd_np):
+    bad = dict(sd_np)
+    bad.pop("backbone.layer2.0.conv1.weight")
+    bad["classifier.5.weight"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(RuntimeError) as e:
+        pack_state_dict(bad, "fp32")
+    msg = str(e.value)
+    assert "Missing key(s)" in msg and "backbone.layer2.0.conv1.weight" in msg
+    assert "Unexpected key(s)" in msg and "classifier.5.weight" in msg
+    wrong = dict(sd_np)
+    wrong["classifier.4.weight"] = np.zeros((2, 512, 1, 1), np.float32)   # a "2-class head" is not this model
+    with pytest.raises(RuntimeError, match="mismatch"):
+        pack_state_dict(wrong, "bf16")
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
+    blob = pack_state_dict(sd_np, precision)
+    prec = 0 if precision == "fp32" else 1
+    assert blob.nbytes == built_lib.nbc_packed_weights_bytes(prec)
+    eb = 4 if prec == 0 else 2
+    off = 0
+
+    def align(v):
+        return (v + 255) // 256 * 256
+
+    for u in topology.conv_units():
+        w = sd_np[u.name + ".weight"]
+        if u.bn is None:
+            got = blob[off: off + w.size * 4].view(np.float32).reshape(3, 512)
+            np.testing.assert_array_equal(got, w.reshape(3, 512))
+            off = align(off + w.size * 4)
+            np.testing.assert_array_equal(blob[off: off + 12].view(np.float32), sd_np[u.name + ".bias"])
+            off = align(off + 12)
+            continue
+        if u.cin == 3:
+            cin_pad, ksteps = 16 // eb, 7
+        else:
+            cin_pad, ksteps = u.cin, u.k * u.k * u.cin * eb // 128
+        row = ksteps * 128 // eb
+        raw = blob[off: off + u.cout * ksteps * 128]
+        got = raw.view(np.float32) if prec == 0 else _bf16_to_f32(raw.view(np.uint16))
+        got = got.reshape(u.cout, row)
+        want = np.zeros((u.cout, row), np.float32)
+        khkwci = w.transpose(0, 2, 3, 1)                       # [O][kh][kw][I]
+        for tap in range(u.k * u.k):
+            want[:, tap * cin_pad: tap * cin_pad + u.cin] = khkwci[:, tap // u.k, tap % u.k, :]
+        if prec == 1:
+            want = torch.from_numpy(want).to(torch.bfloat16).float().numpy()   # RNE like the packer
+        np.testing.assert_array_equal(got, want, err_msg=u.name)
+        off = align(off + u.cout * ksteps * 128)
+        scale = blob[off: off + u.cout * 4].view(np.float32)
+        off = align(off + u.cout * 4)
+        shift = blob[off: off + u.cout * 4].view(np.float32)
+        off = align(off + u.cout * 4)
+        g, b = sd_np[u.bn + ".weight"], sd_np[u.bn + ".bias"]
+        mu, var = sd_np[u.bn + ".running_mean"], sd_np[u.bn + ".running_var"]
+        inv = np.float32(1.0) / np.sqrt(var + np.float32(1e-5), dtype=np.float32)
+        np.testing.assert_array_equal(scale, g * inv)
+        np.testing.assert_array_equal(shift, b - mu * (g * inv))
+    assert off == blob.nbytes
+
+
+def test_model_fails_loudly_without_gpu(built_lib, sd_np):
+    m = FCNResNet50("fp32")
+    assert m.eval() is m
+    with pytest.raises(RuntimeError):
+        m.to("cpu")                                 # the CPU path is the reference, not this package
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m.to("cuda:0")                          # nbc_create reports the missing device
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 16, 16))                # no context / weights
+    with pytest.raises(RuntimeError):
+        FCNResNet50("fp32").train(True)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libnbc_hip.so"))
+    with pytest.raises(RuntimeError, match="only implementation"):
+        FCNResNet50("fp32")

@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the ctypes host wrapper) against the CPU
+oracle on the same seeded inputs and against the committed goldens.
+
+Tolerances (stated here, used below):
+  * fp32 mode ("parity mode", v_mfma_f32_32x32x2_f32): every conv unit's output and the final
+    logits agree with the oracle to LOGIT_RTOL_FP32 of the tensor's max magnitude (the two sides
+    sum the same f32 products in different orders; oneDNN's blocked order cannot be reproduced).
+    Labels are integers and must be IDENTICAL wherever the oracle's top-2 logit margin exceeds
+    twice the measured logit error; pixels inside that band are exact ties up to f32 rounding and
+    are counted and bounded (MAX_TIE_FLIPS_FRAC).
+  * bf16 mode ("throughput mode"): logits within LOGIT_RTOL_BF16; label agreement >= 98 %, every
+    disagreement at an oracle margin below BF16_MARGIN_BAND of the logit range.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, load_golden_labels
+from neuralbarkcalculator_amd import synth
+from neuralbarkcalculator_amd.model import FCNResNet50
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_RTOL_FP32 = 2e-5
+LAYER_RTOL_FP32 = 2e-5
+LOGIT_RTOL_BF16 = 4e-2
+LAYER_RTOL_BF16 = 4e-2
+MAX_TIE_FLIPS_FRAC = 2e-5
+BF16_MARGIN_BAND = 0.10
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def gpu_fp32(built_lib, sd_np):
+    return FCNResNet50("fp32").load_state_dict(sd_np).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def gpu_bf16(built_lib, sd_np):
+    return FCNResNet50("bf16").load_state_dict(sd_np).to(DEV)
+
+
+def frames(idx, h, w):
+    return torch.from_numpy(np.stack([synth.make_input(int(i), h, w) for i in idx]))
+
+
+def oracle_run(oracle_model, x, exclude_nodes=False):
+    from oracle.fcn_resnet50_oracle import predict_labels
+    return predict_labels(oracle_model, x, exclude_nodes)
+
+
+def check_labels(labels_gpu, labels_ref, logits_ref, err, band_scale=2.0, max_frac=MAX_TIE_FLIPS_FRAC):
+    """Integer labels: identical outside the tie band, bounded inside it."""
+    top2 = torch.topk(logits_ref, 2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    mism = labels_gpu.cpu() != labels_ref
+    n_mism = int(mism.sum())
+    if n_mism:
+        worst = float(margin[mism].max())
+        assert worst <= band_scale * err, f"{n_mism} label flips, one at oracle margin {worst} > {band_scale}*{err}"
+    assert n_mism <= max(2, max_frac * mism.numel()), f"{n_mism} label flips of {mism.numel()}"
+    return n_mism
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_every_conv_unit_against_oracle(oracle_model, gpu_fp32, gpu_bf16, mode):
+    """Layer-by-layer parity at 128x128 (every conv unit incl. fused BN/ReLU/residual, max-pool)."""
+    from oracle.fcn_resnet50_oracle import layer_outputs
+    model = gpu_fp32 if mode == "fp32" else gpu_bf16
+    rtol = LAYER_RTOL_FP32 if mode == "fp32" else LAYER_RTOL_BF16
+    x = frames([3], 128, 128)
+    ref = layer_outputs(oracle_model, x)
+    model.set_keep_activations(True)
+    try:
+        lowres = model.lowres_logits(x.to(DEV))
+        torch.cuda.synchronize()
+        report = []
+        for name, want in ref.items():
+            if name == "classifier.4":
+                got = lowres.cpu().numpy()
+            else:
+                got = model.read_activation(name, want.numel())
+            want = want.numpy()
+            assert got.shape == want.shape, name
+            scale = float(np.abs(want).max())
+            err = float(np.abs(got - want).max())
+            report.append((name, err / scale))
+            assert err <= rtol * scale, f"{name}: max err {err} vs scale {scale} ({mode})"
+        print(mode, "worst layer rel err", max(report, key=lambda t: t[1]))
+    finally:
+        model.set_keep_activations(False)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c128_layers.npz"), allow_pickle=False)
+    assert list(g["names"]) == list(ref.keys())
+
+
+@pytest.mark.parametrize("name", ["c128", "b2_256", "odd_h", "h520", "full1024"])
+def test_fp32_end_to_end_vs_oracle_and_goldens(oracle_model, gpu_fp32, name):
+    g = load_golden(name)
+    h, w = (int(v) for v in g["hw"])
+    x = frames(g["frames"], h, w)
+    labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
+    xd = x.to(DEV)
+    labels, counts, lowres = gpu_fp32.predict_labels(xd, return_lowres=True)
+    logits = gpu_fp32(xd)
+    torch.cuda.synchronize()
+    scale = float(logits_ref.abs().max())
+    err_low = float((lowres.cpu() - lowres_ref).abs().max())
+    err = float((logits.cpu() - logits_ref).abs().max())
+    assert err_low <= LOGIT_RTOL_FP32 * scale, (err_low, scale)
+    assert err <= LOGIT_RTOL_FP32 * scale, (err, scale)
+    # committed golden low-res logits (made in the build container): same bound
+    assert float(np.abs(lowres.cpu().numpy() - g["lowres"]).max()) <= 2 * LOGIT_RTOL_FP32 * scale
+    assert labels.dtype == torch.int64 and labels.shape == labels_ref.shape
+    flips = check_labels(labels, labels_ref, logits_ref, max(err, 1e-7 * scale))
+    # the labels are the argmax of the logits the same library returns
+    assert torch.equal(labels, torch.argmax(logits, dim=1))
+    # counts are exact integers of the GPU's own labels
+    want_counts = torch.stack([(labels == c).flatten(1).sum(1) for c in range(3)], 1)
+    assert torch.equal(counts, want_counts)
+    assert int((counts.cpu() - counts_ref).abs().max()) <= flips
+    for b in range(len(g["frames"])):
+        gl = torch.from_numpy(load_golden_labels(name, b).astype(np.int64))
+        assert int((labels[b].cpu() != gl).sum()) <= max(2, MAX_TIE_FLIPS_FRAC * gl.numel())
+    print(name, "logit err", err, "scale", scale, "label flips", flips)
+
+
+@pytest.mark.parametrize("name", ["c128", "b2_256", "full1024"])
+def test_bf16_end_to_end_vs_oracle(oracle_model, gpu_bf16, name):
+    g = load_golden(name)
+    h, w = (int(v) for v in g["hw"])
+    x = frames(g["frames"], h, w)
+    labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
+    xd = x.to(DEV)
+    labels, counts = gpu_bf16.predict_labels(xd, labels_dtype=torch.uint8)
+    logits = gpu_bf16(xd)
+    torch.cuda.synchronize()
+    scale = float(logits_ref.abs().max())
+    err = float((logits.cpu() - logits_ref).abs().max())
+    assert err <= LOGIT_RTOL_BF16 * scale, (err, scale)
+    mism = labels.cpu().long() != labels_ref
+    agree = 1.0 - float(mism.float().mean())
+    top2 = torch.topk(logits_ref, 2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    assert agree >= 0.98, agree
+    if mism.any():
+        assert float(margin[mism].max()) <= BF16_MARGIN_BAND * scale
+    assert int(counts.sum()) == labels.numel()
+    print(name, "bf16 logit err", err, "scale", scale, "agreement", agree)
+
+
+def test_exclude_nodes_and_u8_labels(oracle_model, gpu_fp32):
+    x = frames([3], 128, 128)
+    l_ref, c_ref, logits_ref, _ = oracle_run(oracle_model, x, exclude_nodes=True)
+    labels, counts = gpu_fp32.predict_labels(x.to(DEV), exclude_nodes=True, labels_dtype=torch.uint8)
+    assert labels.dtype == torch.uint8 and int((labels == 2).sum()) == 0 and int(counts[0, 2]) == 0
+    l_plain, c_plain = gpu_fp32.predict_labels(x.to(DEV))
+    remapped = l_plain.clone()
+    remapped[remapped == 2] = 1                              # models.py:273-276
+    assert torch.equal(remapped, labels.long())
+    assert counts[0].tolist() == [int(c_plain[0, 0]), int(c_plain[0, 1] + c_plain[0, 2]), 0]
+    assert int((labels.cpu().long() != l_ref).sum()) <= 2
+
+
+def test_uint8_ingest_equals_float_input(gpu_fp32):
+    """NBC_IN_U8_NHWC applies ToTensor + Normalize (dataset.py:175-186) bit-exactly."""
+    img = np.stack([synth.make_frame(11, 136, 200), synth.make_frame(12, 136, 200)])
+    xf = torch.from_numpy(np.stack([synth.normalize_frame(i) for i in img])).to(DEV)
+    xu = torch.from_numpy(img).to(DEV)
+    a = gpu_fp32(xf)
+    b = gpu_fp32(xu)
+    assert torch.equal(a, b)
+
+
+def test_batch_equals_singles_and_is_deterministic(gpu_fp32, gpu_bf16):
+    x = frames([4, 5, 6], 96, 160).to(DEV)
+    for m in (gpu_fp32, gpu_bf16):
+        full = m(x)
+        again = m(x)
+        assert torch.equal(full, again)
+        for b in range(3):
+            assert torch.equal(m(x[b:b + 1])[0], full[b])
+
+
+def test_upsample_argmax_known_answers(gpu_fp32):
+    """Bicubic taps, border clamping, tie and NaN rules on crafted low-res logits."""
+    dev = torch.device(DEV)
+    # (1) a delta reproduces the closed-form x8 taps
+    z = torch.zeros(1, 3, 5, 9, device=dev)
+    z[0, 0, 2, 4] = 1.0
+    labels, counts, logits = gpu_fp32.upsample_argmax(z, (40, 72), return_logits=True)
+    ref = torch.nn.functional.interpolate(z.cpu(), size=(40, 72), mode="bicubic", align_corners=False)
+    assert float((logits.cpu() - ref).abs().max()) <= 1e-6
+    assert abs(float(logits[0, 0, 20, 36]) - 0.99151611 * 0.99151611) < 1e-6
+    # (2) random logits, non-integer scale, against torch's CPU bicubic + argmax
+    g = torch.Generator().manual_seed(5)
+    lr = torch.randn(2, 3, 26, 128, generator=g)
+    labels, counts, logits = gpu_fp32.upsample_argmax(lr.to(dev), (203, 1024), return_logits=True)
+    ref = torch.nn.functional.interpolate(lr, size=(203, 1024), mode="bicubic", align_corners=False)
+    err = float((logits.cpu() - ref).abs().max())
+    assert err <= 2e-6 * float(ref.abs().max()), err
+    check_labels(labels, torch.argmax(ref, 1), ref, max(err, 1e-7))
+    assert int(counts.sum()) == 2 * 203 * 1024
+    # (3) ties -> lowest index; NaN wins (constant planes stay constant under bicubic: taps sum to 1)
+    c = torch.zeros(1, 3, 4, 4, device=dev)
+    c[0, 1] = 0.0
+    lab, cnt = gpu_fp32.upsample_argmax(c, (32, 32))
+    assert int(lab.sum()) == 0 and cnt[0].tolist() == [1024, 0, 0]
+    c[0, 0] = 1.0
+    c[0, 1] = 2.0
+    c[0, 2] = 2.0
+    lab, cnt = gpu_fp32.upsample_argmax(c, (32, 32))
+    assert bool((lab == 1).all())
+    c[0, 2] = float("nan")
+    lab, cnt = gpu_fp32.upsample_argmax(c, (32, 32))
+    assert bool((lab == 2).all()) and cnt[0].tolist() == [0, 0, 1024]
+    c[0, 1] = float("nan")
+    lab, _ = gpu_fp32.upsample_argmax(c, (32, 32), labels_dtype=torch.uint8)
+    assert bool((lab == 1).all())
+    lab, cnt = gpu_fp32.upsample_argmax(c, (32, 32), exclude_nodes=True)
+    assert bool((lab == 1).all())
+
+
+def test_full_size_properties_1024(gpu_fp32, gpu_bf16):
+    """Size-independent properties at BASELINE.json's full frame size."""
+    x = frames([20, 21], 1024, 1024).to(DEV)
+    for m in (gpu_fp32, gpu_bf16):
+        labels, counts = m.predict_labels(x, labels_dtype=torch.uint8)
+        logits = m(x)
+        assert torch.equal(labels.long(), torch.argmax(logits, 1))
+        assert counts.sum(1).tolist() == [1024 * 1024] * 2
+        assert (counts > 0.02 * 1024 * 1024).all(), counts           # all three classes present
+        l2, c2 = m.predict_labels(x[1:2], labels_dtype=torch.uint8)
+        assert torch.equal(l2[0], labels[1]) and torch.equal(c2[0], counts[1])
+    a = gpu_fp32.predict_labels(x, labels_dtype=torch.uint8)[0]
+    b = gpu_bf16.predict_labels(x, labels_dtype=torch.uint8)[0]
+    assert float((a == b).float().mean()) > 0.98
+
+
+def test_errors_are_python_exceptions(gpu_fp32):
+    with pytest.raises(RuntimeError):
+        gpu_fp32(torch.zeros(1, 3, 4, 4, device=DEV))          # H, W >= 8
+    with pytest.raises(RuntimeError):
+        gpu_fp32(torch.zeros(1, 4, 16, 16, device=DEV))
+    with pytest.raises(RuntimeError):
+        gpu_fp32(torch.zeros(1, 3, 16, 16))                    # wrong device
+    with pytest.raises(RuntimeError):
+        FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
