@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Throughput bench of the hot path: 1024x1024 images/s through libnbc_hip.so.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N>1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` with one rank per GPU.  A *step* is one
+pass of the hot path (model call + argmax + class counts, models.py:269-270,324-331) over one batch
+of synthetic frames that are already resident in HBM.  W untimed warm-up steps, then exactly K
+steps bracketed by barrier + torch.cuda.synchronize() on both sides; the time is the MAX over
+ranks; rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): 1 x MI355X, batch 1, random-init fcn_resnet50, synthetic
+1024x1024x3 frames.  Images are independent, so N GPUs = N shards of the folder with
+no data-path collective: scaling is weak, the only collective is the one-off RCCL broadcast of the
+packed weights (outside the timed region, reported as ``setup``).
+
+Extra objects on the same line: ``roofline`` (dominant kernel = the implicit-GEMM convolution,
+MFMA-bound; per-launch HIP-event times taken inside the timed region), ``cpu_baseline`` (the torch
+CPU oracle on this box's host cores, a bounded sample), ``parity`` (label match of this run's
+precision against the oracle on the sample frame).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from neuralbarkcalculator_amd import synth  # noqa: E402
+from neuralbarkcalculator_amd.model import FCNResNet50  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+H = W = 1024
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--weights", choices=["random_init", "trained_like"], default="trained_like")
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-op-events", action="store_true", help="timed region without per-launch HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, frame):
+    """The oracle (a port of the reference's torch-CPU forward, eval mode) + argmax, timed on this
+    box's host cores: 1 warm-up + 3 timed calls on ONE 1024x1024 frame (about 10-30 s of CPU work)."""
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50, predict_labels
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)                       # predict.py:78-79
+    m = OracleFCNResNet50()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = torch.from_numpy(frame)[None]
+    out = predict_labels(m, x)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = predict_labels(m, x)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {"value": 1.0 / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 synthetic 1024x1024 frame, torch %s CPU oracle (eval) + argmax, 1 warm-up + median of 3"
+                      % torch.__version__,
+            "s_per_image": med}, out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    t_setup0 = time.perf_counter()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    # weights: rank 0 builds + packs the state_dict, everyone else receives the packed blob (RCCL)
+    model = FCNResNet50(args.precision)
+    sd = None
+    if rank == 0:
+        sd = synth.make_state_dict(args.weights, seed=7)
+        model.load_state_dict(sd)
+    model.to(dev)
+    if world > 1:
+        model.broadcast_weights(src=0)
+    # frames: each rank owns its shard of the folder (rank r takes global images r, r+world, ...)
+    nf = max(1, args.frames)
+    frames = [synth.make_input(rank + world * i, H, W) for i in range(nf)]
+    batches = []
+    for i in range(nf):
+        b = np.stack([frames[(i + j) % nf] for j in range(args.batch)])
+        batches.append(torch.from_numpy(b).to(dev))
+    model.reserve(args.batch, H, W)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def step(i):
+        return model.predict_labels(batches[i % nf], labels_dtype=torch.uint8)
+
+    use_events = not args.no_op_events
+    if use_events:
+        model.set_profiling(True)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if use_events:
+        model.op_records()          # drop the warm-up samples
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    records = model.op_records() if use_events else []
+    model.set_profiling(False)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    images = world * args.batch * args.steps
+    out = {
+        "metric": "1024x1024 images/sec (whole node) + per-pixel label match vs CPU ref",
+        "value": images / dt,
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.precision if args.precision == "bf16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: 1xMI355X per rank, batch=%d, %s fcn_resnet50 (eval), synthetic "
+                               "1024x1024x3 frames resident in HBM, forward+argmax+class counts" % (args.batch, args.weights),
+                   "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank"},
+        "setup_s": t_setup,
+    }
+
+    if records:
+        conv = [r for r in records if r["kernel"] == "conv_igemm"]
+        dom = [r for r in conv if r["cout"] % 128 == 0 and r["name"] != "backbone.conv1"]   # wide-tile instantiation
+        flops = sum(r["flops"] for r in dom)
+        ms = sum(r["ms"] for r in dom)
+        c3 = [r for r in conv if r["k"] == 3]
+        tot_ms = sum(r["ms"] for r in records)
+        ach = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "conv_igemm_kernel<%s,BN=128> (all non-stem convs with Cout%%128==0)" % args.precision,
+            "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+            "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None,
+            "launches_per_step": len(dom), "flops_per_step": flops, "avg_launch_ms": ms / max(1, len(dom)),
+            "conv3x3_tflops": sum(r["flops"] for r in c3) / (sum(r["ms"] for r in c3) * 1e-3) / 1e12,
+            "conv3x3_frac": sum(r["flops"] for r in c3) / (sum(r["ms"] for r in c3) * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision],
+            "all_conv_tflops": sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12,
+            "sum_kernel_ms_per_step": tot_ms,
+        }
+        worst = sorted(records, key=lambda r: -r["ms"])[:6]
+        out["top_ops"] = [{"name": r["name"], "ms": round(r["ms"], 4),
+                           "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 else 0} for r in worst]
+
+    if not args.no_cpu_baseline or not args.no_parity:
+        base, ref = cpu_baseline(sd, frames[0])
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = base
+        if not args.no_parity:
+            labels_ref = ref[0]
+            labels, counts = model.predict_labels(torch.from_numpy(frames[0])[None].to(dev))
+            torch.cuda.synchronize()
+            mism = int((labels.cpu() != labels_ref).sum())
+            out["parity"] = {"frame": "synthetic frame 0 (rank 0)", "label_mismatches": mism,
+                             "pixels": int(labels_ref.numel()), "label_match": 1.0 - mism / labels_ref.numel(),
+                             "oracle_class_counts": ref[1][0].tolist(), "gpu_class_counts": counts[0].cpu().tolist()}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

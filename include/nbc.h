@@ -84,10 +84,12 @@ typedef struct {
 typedef struct {
   char name[64];      /* conv unit name, or "ingest" / "maxpool" / "upsample_argmax" */
   char kernel[32];    /* kernel family: "conv_igemm", "head1x1", ... */
-  float ms;           /* HIP-event time around the launch on the forward's stream */
+  float ms;           /* mean HIP-event time around the launch on the forward's stream */
+  int32_t calls;      /* forwards averaged over */
   double flops;       /* algorithmic: 2*MAC of the convolution (0 for non-conv ops) */
   double bytes;       /* algorithmic: input read once + weights once + output once (+ identity) */
   int32_t kh, kw;     /* kernel extent (0 for non-conv) */
+  int32_t cout;       /* output channels (conv ops): Co % 128 == 0 selects the wide-tile kernel */
 } nbc_op_record;
 
 const char* nbc_last_error(void);
@@ -152,7 +154,10 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
 int nbc_set_keep_activations(nbc_ctx* ctx, int on);
 int nbc_read_activation(nbc_ctx* ctx, const char* name, float* dst_host, size_t capacity,
                         int64_t shape[4]);
-/* When on, every launch of the next forwards is bracketed by HIP events on the stream. */
+/* When on, every launch of the next forwards is bracketed by HIP events on the forward's stream
+ * (no synchronisation inside nbc_forward).  nbc_num_op_records() waits for the last profiled
+ * forward, averages each launch over all forwards profiled since the previous call, resets the
+ * accumulation and returns the number of records (one per launch of the plan). */
 int nbc_set_profiling(nbc_ctx* ctx, int on);
 int nbc_num_op_records(nbc_ctx* ctx);
 int nbc_get_op_record(nbc_ctx* ctx, int index, nbc_op_record* out);

@@ -32,8 +32,9 @@ class NbcConvDesc(C.Structure):
 
 
 class NbcOpRecord(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("kernel", C.c_char * 32), ("ms", C.c_float),
-                ("flops", C.c_double), ("bytes", C.c_double), ("kh", C.c_int32), ("kw", C.c_int32)]
+    _fields_ = [("name", C.c_char * 64), ("kernel", C.c_char * 32), ("ms", C.c_float), ("calls", C.c_int32),
+                ("flops", C.c_double), ("bytes", C.c_double), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("cout", C.c_int32)]
 
 
 # every symbol include/nbc.h declares: (restype, argtypes)

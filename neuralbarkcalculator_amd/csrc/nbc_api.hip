@@ -63,7 +63,11 @@ struct nbc_ctx {
   size_t lowres_cap = 0;
   bool keep = false;
   bool profiling = false;
-  std::vector<hipEvent_t> events;
+  // profiling: one event set (nops+1 events) per profiled forward, read back lazily so that the
+  // timed loop never synchronises; nbc_num_op_records() averages over the sets and resets.
+  std::vector<std::vector<hipEvent_t>> prof_sets;
+  size_t prof_used = 0;
+  std::vector<Op> prof_ops;
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
 };
@@ -243,7 +247,7 @@ int nbc_destroy(nbc_ctx* c) {
   for (void* b : c->bufs) if (b) (void)hipFree(b);
   if (c->lowres) (void)hipFree(c->lowres);
   if (c->owned_weights) (void)hipFree(c->owned_weights);
-  for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+  for (auto& set : c->prof_sets) for (hipEvent_t ev : set) (void)hipEventDestroy(ev);
   delete c;
   return NBC_OK;
 }
@@ -328,16 +332,22 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
   const int prec = c->precision;
 
   const size_t nops = P.ops.size();
-  if (c->profiling && c->events.size() < nops + 1) {
-    while (c->events.size() < nops + 1) {
+  constexpr size_t kMaxProfSets = 4096;
+  std::vector<hipEvent_t>* evs = nullptr;
+  if (c->profiling && c->prof_used < kMaxProfSets) {
+    if (c->prof_used > 0 && c->prof_ops.size() != nops) c->prof_used = 0;   // plan changed: restart
+    if (c->prof_sets.size() <= c->prof_used) c->prof_sets.emplace_back();
+    evs = &c->prof_sets[c->prof_used];
+    while (evs->size() < nops + 1) {
       hipEvent_t ev;
       NBC_HIP(hipEventCreate(&ev));
-      c->events.push_back(ev);
+      evs->push_back(ev);
     }
+    c->prof_ops = P.ops;
   }
   float* lowres = logits_lowres_dev ? logits_lowres_dev : c->lowres;
 
-  if (c->profiling) NBC_HIP(hipEventRecord(c->events[0], s));
+  if (evs) NBC_HIP(hipEventRecord((*evs)[0], s));
   for (size_t i = 0; i < nops; ++i) {
     const Op& o = P.ops[i];
     hipError_t e = hipSuccess;
@@ -392,25 +402,44 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
     }
     if (e != hipSuccess)
       return set_error(NBC_ERR_HIP, "launch of " + o.name + " failed: " + hipGetErrorString(e));
-    if (c->profiling) NBC_HIP(hipEventRecord(c->events[i + 1], s));
+    if (evs) NBC_HIP(hipEventRecord((*evs)[i + 1], s));
   }
-
-  if (c->profiling) {
-    NBC_HIP(hipEventSynchronize(c->events[nops]));
-    c->records.assign(nops, nbc_op_record{});
-    for (size_t i = 0; i < nops; ++i) {
-      const Op& o = P.ops[i];
-      nbc_op_record& r = c->records[i];
-      std::snprintf(r.name, sizeof(r.name), "%s", o.name.c_str());
-      std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel_name(o.kind));
-      NBC_HIP(hipEventElapsedTime(&r.ms, c->events[i], c->events[i + 1]));
-      r.flops = o.flops;
-      r.bytes = o.bytes;
-      r.kh = r.kw = (o.kind == OP_CONV || o.kind == OP_HEAD1X1) ? units[o.unit].k : 0;
-    }
-  }
+  if (evs) ++c->prof_used;
   return NBC_OK;
 }
+
+}  // extern "C"
+
+// Average the event sets recorded since the last call (synchronises on the last one), then reset.
+static int collect_profile(nbc_ctx* c) {
+  if (c->prof_used == 0) return NBC_OK;
+  const auto& units = conv_units();
+  const size_t nops = c->prof_ops.size();
+  NBC_HIP(hipEventSynchronize(c->prof_sets[c->prof_used - 1][nops]));
+  c->records.assign(nops, nbc_op_record{});
+  for (size_t i = 0; i < nops; ++i) {
+    const Op& o = c->prof_ops[i];
+    nbc_op_record& r = c->records[i];
+    std::snprintf(r.name, sizeof(r.name), "%s", o.name.c_str());
+    std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel_name(o.kind));
+    double sum = 0.0;
+    for (size_t k = 0; k < c->prof_used; ++k) {
+      float ms = 0.f;
+      NBC_HIP(hipEventElapsedTime(&ms, c->prof_sets[k][i], c->prof_sets[k][i + 1]));
+      sum += ms;
+    }
+    r.ms = (float)(sum / (double)c->prof_used);
+    r.calls = (int32_t)c->prof_used;
+    r.flops = o.flops;
+    r.bytes = o.bytes;
+    r.kh = r.kw = (o.kind == OP_CONV || o.kind == OP_HEAD1X1) ? units[o.unit].k : 0;
+    r.cout = o.Co;
+  }
+  c->prof_used = 0;
+  return NBC_OK;
+}
+
+extern "C" {
 
 int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, int H, int W,
                         float* logits_full_dev, void* labels_dev, int labels_dtype,
@@ -427,7 +456,11 @@ int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, in
   return NBC_OK;
 }
 
-int nbc_num_op_records(nbc_ctx* c) { return c ? (int)c->records.size() : 0; }
+int nbc_num_op_records(nbc_ctx* c) {
+  if (!c) return 0;
+  if (collect_profile(c) != NBC_OK) return NBC_ERR_HIP;
+  return (int)c->records.size();
+}
 
 int nbc_get_op_record(nbc_ctx* c, int index, nbc_op_record* out) {
   if (!c || !out || index < 0 || index >= (int)c->records.size())

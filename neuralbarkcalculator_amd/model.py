@@ -219,10 +219,14 @@ class FCNResNet50:
         """Per-launch (name, kernel, ms, flops, bytes, k) of the last profiled forward."""
         out = []
         rec = _lib.NbcOpRecord()
-        for i in range(self._lib.nbc_num_op_records(self._require_ctx())):
+        n = self._lib.nbc_num_op_records(self._require_ctx())
+        if n < 0:
+            _lib.check(n, "nbc_num_op_records")
+        for i in range(n):
             _lib.check(self._lib.nbc_get_op_record(self._ctx, i, C.byref(rec)))
             out.append(dict(name=rec.name.decode(), kernel=rec.kernel.decode(), ms=float(rec.ms),
-                            flops=float(rec.flops), bytes=float(rec.bytes), k=int(rec.kh)))
+                            calls=int(rec.calls), flops=float(rec.flops), bytes=float(rec.bytes),
+                            k=int(rec.kh), cout=int(rec.cout)))
         return out
 
     def set_keep_activations(self, on: bool):
