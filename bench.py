@@ -53,12 +53,24 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("NBC_CPU_BASELINE_THREADS", "16")))   # GPU-box share per GPU is 16
+
+
 def cpu_baseline(sd, frame):
     """The oracle (a port of the reference's torch-CPU forward, eval mode) + argmax, timed on this
     box's host cores: 1 warm-up + 3 timed calls on ONE 1024x1024 frame (about 10-30 s of CPU work)."""
     from oracle.fcn_resnet50_oracle import OracleFCNResNet50, predict_labels
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)                       # predict.py:78-79
+    cores = host_cores()
+    torch.set_num_threads(cores)                       # predict.py:78-79 (cpu_count(), capped to our share)
     m = OracleFCNResNet50()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     x = torch.from_numpy(frame)[None]

@@ -27,6 +27,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int BM = 128;
 constexpr int THREADS = 256;
@@ -81,10 +82,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
   // ---- loader geometry: thread -> (chunk lc of the K-step, rows lr + 32 i)
   const int lc = tid & 7;
   const int lr = tid >> 3;
-  const unsigned char* xb = static_cast<const unsigned char*>(p.x);
-  const unsigned char* wb = static_cast<const unsigned char*>(p.w);
   const int pix_bytes = p.Ci * EB;
-  const size_t wrow_bytes = (size_t)p.ksteps * 128;
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
 
   int a_iy0[4], a_ix0[4], a_img[4];
   {
@@ -107,14 +106,19 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
       }
     }
   }
-  const unsigned char* wrow[B_ROWS];
+  unsigned wrow[B_ROWS];          // byte offset of this thread's chunk in weight row n, K-step 0
 #pragma unroll
-  for (int i = 0; i < B_ROWS; ++i) wrow[i] = wb + (size_t)(n0 + lr + 32 * i) * wrow_bytes + lc * 16;
+  for (int i = 0; i < B_ROWS; ++i) wrow[i] = (unsigned)(n0 + lr + 32 * i) * wrow_bytes + lc * 16;
+  // buffer descriptors (wave-uniform: kernel arguments only); 32-bit byte offsets, range-checked
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+  constexpr unsigned kOOB = 0x80000000u;   // every buffer is < 2 GiB (checked on the host)
 
   const int cblocks = STEM ? 1 : pix_bytes / 128;   // K-steps per tap
   int ld_kh = 0, ld_kw = 0, ld_cb = 0;              // position of the next K-step to load
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  uint4 ra[4], rb[B_ROWS];
+  u32x4 ra[4], rb[B_ROWS];
 
   auto load_step = [&](int t) {
     if constexpr (!STEM) {
@@ -124,8 +128,11 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
       for (int i = 0; i < 4; ++i) {
         const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
         const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const size_t off = (size_t)(a_img[i] + iy * p.Wi + ix) * pix_bytes + coff;
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(xb + off) : zero4;
+        // halo / tail lanes get an out-of-range buffer offset: the hardware range check returns
+        // zeros, the load itself stays unconditional (a select around a plain load makes hipcc
+        // branch around it and drain vmcnt per element)
+        const unsigned off = (unsigned)(a_img[i] + iy * p.Wi + ix) * (unsigned)pix_bytes + (unsigned)coff;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? off : kOOB, 0, 0);
       }
       if (++ld_cb == cblocks) {
         ld_cb = 0;
@@ -139,13 +146,13 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
       for (int i = 0; i < 4; ++i) {
         const int iy = a_iy0[i] + kh * p.dil, ix = a_ix0[i] + kw * p.dil;
         const bool ok = tap_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const size_t off = (size_t)(a_img[i] + iy * p.Wi + ix) * 16;
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(xb + off) : zero4;
+        const unsigned off = (unsigned)(a_img[i] + iy * p.Wi + ix) * 16u;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? off : kOOB, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i)
-      rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)t * 128);
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wrow[i] + (unsigned)t * 128u, 0, 0);
   };
 
   auto store_step = [&](int stage) {
@@ -153,10 +160,10 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
     unsigned char* sb = sa + A_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(sa + lds_off(lr + 32 * i, lc)) = ra[i];
+      *reinterpret_cast<u32x4*>(sa + lds_off(lr + 32 * i, lc)) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i)
-      *reinterpret_cast<uint4*>(sb + lds_off(lr + 32 * i, lc)) = rb[i];
+      *reinterpret_cast<u32x4*>(sb + lds_off(lr + 32 * i, lc)) = rb[i];
   };
 
   // ---- MFMA geometry
@@ -283,6 +290,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s) {
   // Shapes the kernel assumes (checked on the host so that a bad plan can never reach the GPU).
   const int eb = precision == 0 ? 4 : 2;
   if (a.M <= 0 || a.Co % 64 != 0 || a.ksteps <= 0) return hipErrorInvalidValue;
+  if (a.x_bytes == 0 || a.x_bytes >= 0x80000000u || a.w_bytes == 0 || a.w_bytes >= 0x80000000u)
+    return hipErrorInvalidValue;     // 32-bit range-checked buffer offsets
   if (a.stem) {
     if (a.Ci * eb != 16 || a.ksteps * 8 < a.KH * a.KW) return hipErrorInvalidValue;
   } else {

@@ -368,6 +368,14 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
         a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
         a.y = c->bufs[o.out_buf];
+        {
+          const size_t xb = (size_t)N * o.Hi * o.Wi * o.Ci * elem_bytes(prec);
+          const size_t wbts = (size_t)o.Co * pc.ksteps * kKStepBytes;
+          if (xb >= 0x80000000ull || wbts >= 0x80000000ull)
+            return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
+          a.x_bytes = (unsigned)xb;
+          a.w_bytes = (unsigned)wbts;
+        }
         a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
         a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
         a.KH = u.k; a.KW = u.k; a.stride = u.stride; a.pad = u.pad; a.dil = u.dil;

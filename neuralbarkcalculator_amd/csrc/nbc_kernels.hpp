@@ -15,6 +15,8 @@ struct ConvArgs {
   const float* shift;   // [Co]
   const void* res;      // nullable, [M][Co] elements (the identity of a bottleneck)
   void* y;              // [M][Co] elements
+  unsigned x_bytes;     // size of x in bytes (< 2 GiB): buffer range check = zero fill of the halo
+  unsigned w_bytes;     // size of w in bytes
   int N, Hi, Wi, Ci;
   int Ho, Wo, Co;
   int KH, KW, stride, pad, dil;
