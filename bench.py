@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--weights", choices=["random_init", "trained_like"], default="trained_like")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
+    ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
+    ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0..3 force a tile shape (A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-op-events", action="store_true", help="timed region without per-launch HIP events")
@@ -122,6 +124,7 @@ def main():
         b = np.stack([frames[(i + j) % nf] for j in range(args.batch)])
         batches.append(torch.from_numpy(b).to(dev))
     model.reserve(args.batch, H, W)
+    model.set_conv_impl(args.conv_impl, args.conv_tile)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup0
 
@@ -176,7 +179,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: 1xMI355X per rank, batch=%d, %s fcn_resnet50 (eval), synthetic "
                                "1024x1024x3 frames resident in HBM, forward+argmax+class counts" % (args.batch, args.weights),
-                   "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank"},
+                   "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank",
+                   "conv_impl": args.conv_impl, "conv_tile": args.conv_tile},
         "setup_s": t_setup,
     }
 

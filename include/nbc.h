@@ -148,6 +148,11 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
                         float* logits_full_dev, void* labels_dev, int labels_dtype,
                         int64_t* counts_dev, int exclude_nodes, void* hip_stream);
 
+/* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
+ * register-staged reference kernel; tile = -1 (per-layer choice) or 0..3 = 128x64, 128x128,
+ * 256x128, 256x256 (pixels x channels) forced wherever the layer's Cout allows it. */
+int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
+
 /* ---- debugging / measurement ----------------------------------------------------------- */
 /* Copy the activation written by conv unit `name` during the last forward to `dst_host` as
  * float32 NCHW.  `capacity` is in elements.  Only valid when keep-activations is on. */

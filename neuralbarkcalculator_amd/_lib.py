@@ -60,6 +60,7 @@ SIGNATURES = {
                               C.c_void_p]),
     "nbc_upsample_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "nbc_set_conv_impl": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "nbc_set_keep_activations": (C.c_int, [C.c_void_p, C.c_int]),
     "nbc_read_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_int64 * 4)]),

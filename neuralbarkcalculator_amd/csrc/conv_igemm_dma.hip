@@ -1,0 +1,350 @@
+// Implicit-GEMM convolution, LDS-DMA pipeline ("v2"): the production conv kernel of the path.
+//
+// Same GEMM view, K-step (128 bytes of K per row), LDS image (XOR-swizzled 16-byte chunks) and
+// fused BN(+residual)(+ReLU) epilogue as conv_igemm.hip; what changes is how tiles reach LDS:
+//
+//   * global_load_lds_dwordx4 (LDS-DMA): each lane names a 16-byte SOURCE (a pixel's channel
+//     chunk, a weight-row chunk, or the zero page for padding-halo / tail lanes); the wave's 64
+//     chunks land in 1 KiB of LDS contiguously (8 rows x 128 B).  The swizzle therefore sits on
+//     the source side: physical slot p of row r holds logical chunk p ^ ((r>>1)&7)
+//     (cdna_hip_programming.md rule 21).  No staging VGPRs, no ds_write.
+//   * an S-stage LDS ring with COUNTED s_waitcnt vmcnt(N) and a raw s_barrier, one barrier per
+//     K-step: at the top of step t a wave waits until only the (S-2) youngest K-steps' DMAs are
+//     outstanding (its share of step t has landed), the barrier makes every wave's share visible
+//     and retires the reads of step t-1, then the DMAs of step t+S-1 are issued into the slot
+//     step t-1 used, then the MFMAs of step t run from LDS.
+//     The DMA is issued from inline asm so that hipcc does not pair it with vmcnt(0) drains
+//     (cdna_hip_programming.md section 5, "Pipelining across barriers" and 5.7).
+//   * tile shape is a template parameter chosen per layer on the host (enough tiles to fill 256
+//     CUs at batch 1, the largest tile otherwise: L2->LDS traffic per FLOP falls with tile size).
+//
+// D[n][m] orientation as in v1: weights are the MFMA A operand, pixels the B operand, so a lane
+// ends up holding one pixel (column) and groups of four consecutive output channels (rows).
+#include "nbc_kernels.hpp"
+
+namespace nbc {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
+  return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// One LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_base .. lds_base+1023.
+// M0 carries the wave-uniform LDS base; it is compiler-reserved, so it is saved, written and
+// restored inside the one statement that uses it.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Tile = (WM*MT*32) pixels x (WN*NT*32) channels, WM*WN waves, S LDS stages.
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int EB = PREC == 0 ? 4 : 2;
+  constexpr int THREADS = WM * WN * 64;
+  constexpr int BM = WM * MT * 32;
+  constexpr int BN = WN * NT * 32;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int B_BYTES = BN * 128;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int ROWS_PER_PASS = THREADS / 8;
+  constexpr int A_PASSES = BM / ROWS_PER_PASS;
+  constexpr int B_PASSES = BN / ROWS_PER_PASS;
+  constexpr int L = A_PASSES + B_PASSES;          // DMA instructions per thread per K-step
+  static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must fill whole passes");
+  static_assert(S >= 2 && S <= 4, "2..4 LDS stages");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- tile coordinates (XCD-contiguous, n fastest; see conv_igemm.hip)
+  const int tiles_n = p.Co / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % tiles_n;
+  const int tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- loader geometry: thread -> physical slot ps of the row, rows lr + ROWS_PER_PASS*i.
+  // Wave w's 64 lanes cover rows 8w..8w+7 of a pass = 1 KiB of LDS, linear in the lane.
+  const int ps = tid & 7;
+  const int lr = tid >> 3;
+  const unsigned char* xb = static_cast<const unsigned char*>(p.x);
+  const unsigned char* wb = static_cast<const unsigned char*>(p.w);
+  const unsigned char* zpage = static_cast<const unsigned char*>(p.zero);
+  const int pix_bytes = p.Ci * EB;
+  const size_t wrow_bytes = (size_t)p.ksteps * 128;
+
+  int a_iy0[A_PASSES], a_ix0[A_PASSES], a_img[A_PASSES], a_coff[A_PASSES];
+  {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int row = lr + ROWS_PER_PASS * i;
+      const int m = m0 + row;
+      a_coff[i] = (ps ^ ((row >> 1) & 7)) * 16;     // logical chunk this slot holds
+      if (m < p.M) {
+        const int img = m / hw;
+        const int rem = m - img * hw;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_iy0[i] = oy * p.stride - p.pad;
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_img[i] = img * p.Hi * p.Wi;
+      } else {
+        a_iy0[i] = -(1 << 24);
+        a_ix0[i] = 0;
+        a_img[i] = 0;
+      }
+    }
+  }
+  const unsigned char* wsrc[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int row = lr + ROWS_PER_PASS * i;
+    wsrc[i] = wb + (size_t)(n0 + row) * wrow_bytes + (ps ^ ((row >> 1) & 7)) * 16;
+  }
+
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  const unsigned smem_base = (unsigned)(size_t)(lds_u8*)smem;     // LDS byte offset of the ring
+  const unsigned wave_off = (unsigned)wave * 1024u;
+  const int cblocks = STEM ? 1 : pix_bytes / 128;
+  int ld_kh = 0, ld_kw = 0, ld_cb = 0;
+
+  auto issue_step = [&](int t, int stage) {
+    const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
+    const unsigned sb = sa + A_BYTES;
+    if constexpr (!STEM) {
+      const int dy = ld_kh * p.dil, dx = ld_kw * p.dil;
+      const int cbo = ld_cb * 128;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * pix_bytes + (cbo + a_coff[i]);
+        // arithmetic select keeps the DMA unconditional: halo / tail lanes copy 16 zero bytes
+        const unsigned char* src = ok ? xb + off : zpage;
+        dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
+      }
+      if (++ld_cb == cblocks) {
+        ld_cb = 0;
+        if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) {
+        const int tap = t * 8 + (a_coff[i] >> 4);      // stem: one chunk = one tap's padded pixel
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int iy = a_iy0[i] + kh * p.dil, ix = a_ix0[i] + kw * p.dil;
+        const bool ok = tap < p.KH * p.KW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * 16;
+        const unsigned char* src = ok ? xb + off : zpage;
+        dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i)
+      dma16(wsrc[i] + (size_t)t * 128, sb + (unsigned)(ROWS_PER_PASS * 128 * i));
+  };
+
+  // ---- MFMA geometry
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
+
+  auto compute = [&](int stage) {
+    const unsigned char* sa = smem + stage * STAGE_BYTES;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = 2 * ks + h;
+      uint4 pf[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        pf[i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * MT + i) * 32 + r, chunk));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wf[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if constexpr (PREC == 1) {
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, pf[i]), acc[j][i], 0, 0, 0);
+          } else {
+            const float4 wv = __builtin_bit_cast(float4, wf[j]);
+            const float4 pv = __builtin_bit_cast(float4, pf[i]);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, pv.x, acc[j][i], 0, 0, 0);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, pv.y, acc[j][i], 0, 0, 0);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, pv.z, acc[j][i], 0, 0, 0);
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, acc[j][i], 0, 0, 0);
+          }
+        }
+    }
+  };
+
+  // ---- pipeline.  Steps beyond T issue nothing; the counted wait then over-waits, which is safe
+  // (vmcnt retires in order), and the tail uses vmcnt(0).
+  const int T = p.ksteps;
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < T) issue_step(s, s);
+  for (int t = 0; t < T; ++t) {
+    // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
+    if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
+    compute(t % S);
+  }
+
+  // ---- epilogue (all DMAs retired by the last wait)
+  unsigned char* yb = static_cast<unsigned char*>(p.y);
+  const unsigned char* resb = static_cast<const unsigned char*>(p.res);
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + (wm * MT + i) * 32 + r;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
+        float v[4];
+        v[0] = __builtin_fmaf(acc[j][i][4 * g + 0], sc.x, sh.x);
+        v[1] = __builtin_fmaf(acc[j][i][4 * g + 1], sc.y, sh.y);
+        v[2] = __builtin_fmaf(acc[j][i][4 * g + 2], sc.z, sh.z);
+        v[3] = __builtin_fmaf(acc[j][i][4 * g + 3], sc.w, sh.w);
+        const size_t eoff = ((size_t)m * p.Co + n) * EB;
+        if (resb) {
+          if constexpr (PREC == 0) {
+            const float4 rv = *reinterpret_cast<const float4*>(resb + eoff);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          } else {
+            const ushort4 rv = *reinterpret_cast<const ushort4*>(resb + eoff);
+            v[0] += bf16_bits_to_f32(rv.x); v[1] += bf16_bits_to_f32(rv.y);
+            v[2] += bf16_bits_to_f32(rv.z); v[3] += bf16_bits_to_f32(rv.w);
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : (v[e] != v[e] ? v[e] : 0.f);
+        }
+        if constexpr (PREC == 0) {
+          *reinterpret_cast<float4*>(yb + eoff) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          ushort4 o;
+          o.x = f32_to_bf16_bits(v[0]); o.y = f32_to_bf16_bits(v[1]);
+          o.z = f32_to_bf16_bits(v[2]); o.w = f32_to_bf16_bits(v[3]);
+          *reinterpret_cast<ushort4*>(yb + eoff) = o;
+        }
+      }
+    }
+}
+
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>
+hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  constexpr int smem = S * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (a.Co % BN != 0) return hipErrorInvalidValue;
+  const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(WM * WN * 64), smem, s, a);
+  return hipGetLastError();
+}
+
+template <int PREC, bool STEM>
+hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
+  switch (tile) {
+    case CONV_TILE_128x64:  return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM>(a, s);   // 72 KiB LDS, 2 blocks/CU
+    case CONV_TILE_128x128: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM>(a, s);   // 64 KiB LDS, 2 blocks/CU
+    case CONV_TILE_256x128: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM>(a, s);   // 144 KiB LDS, 8 waves
+    case CONV_TILE_256x256: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM>(a, s);   // 128 KiB LDS, 8 waves
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+int conv_tile_rows(int tile) { return tile == CONV_TILE_128x64 || tile == CONV_TILE_128x128 ? 128 : 256; }
+int conv_tile_cols(int tile) {
+  return tile == CONV_TILE_128x64 ? 64 : (tile == CONV_TILE_256x256 ? 256 : 128);
+}
+
+// Tile choice: the largest tile that still yields at least one tile per CU (256); when no shape
+// does, the one with the most tiles.  Bigger tiles move fewer L2->LDS bytes per FLOP.
+int choose_conv_tile(int M, int Co) {
+  const int order[4] = {CONV_TILE_256x256, CONV_TILE_256x128, CONV_TILE_128x128, CONV_TILE_128x64};
+  int best = -1, best_tiles = -1;
+  for (int k = 0; k < 4; ++k) {
+    const int t = order[k];
+    if (Co % conv_tile_cols(t) != 0) continue;
+    const int tiles = ((M + conv_tile_rows(t) - 1) / conv_tile_rows(t)) * (Co / conv_tile_cols(t));
+    if (tiles >= 256) return t;
+    if (tiles > best_tiles) { best = t; best_tiles = tiles; }
+  }
+  return best;
+}
+
+hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s) {
+  const int eb = precision == 0 ? 4 : 2;
+  if (a.M <= 0 || a.Co % 64 != 0 || a.ksteps <= 0 || a.zero == nullptr) return hipErrorInvalidValue;
+  if (a.stem) {
+    if (a.Ci * eb != 16 || a.ksteps * 8 < a.KH * a.KW) return hipErrorInvalidValue;
+  } else {
+    if ((a.Ci * eb) % 128 != 0 || a.ksteps != a.KH * a.KW * (a.Ci * eb / 128)) return hipErrorInvalidValue;
+  }
+  if (tile < 0) tile = choose_conv_tile(a.M, a.Co);
+  if (tile < 0 || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
+  if (precision == 0) return a.stem ? launch_tile<0, true>(a, tile, s) : launch_tile<0, false>(a, tile, s);
+  return a.stem ? launch_tile<1, true>(a, tile, s) : launch_tile<1, false>(a, tile, s);
+}
+
+}  // namespace nbc

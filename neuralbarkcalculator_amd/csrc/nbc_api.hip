@@ -61,6 +61,9 @@ struct nbc_ctx {
   std::vector<size_t> buf_cap;
   float* lowres = nullptr;
   size_t lowres_cap = 0;
+  void* zero_page = nullptr;                // 256 zero bytes: DMA source of halo / tail lanes
+  int conv_impl = 1;                        // 1 = LDS-DMA ring (v2), 0 = register-staged (v1)
+  int conv_tile = -1;                       // v2 tile override, -1 = per-layer choice
   bool keep = false;
   bool profiling = false;
   // profiling: one event set (nops+1 events) per profiled forward, read back lazily so that the
@@ -237,6 +240,10 @@ int nbc_create(nbc_ctx** out, int hip_device) {
     return set_error(NBC_ERR_HIP, std::string("nbc_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
   nbc_ctx* c = new nbc_ctx();
   c->device = hip_device;
+  if (hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
+    delete c;
+    return set_error(NBC_ERR_NOMEM, "nbc_create: cannot allocate the zero page");
+  }
   *out = c;
   return NBC_OK;
 }
@@ -246,6 +253,7 @@ int nbc_destroy(nbc_ctx* c) {
   (void)hipSetDevice(c->device);
   for (void* b : c->bufs) if (b) (void)hipFree(b);
   if (c->lowres) (void)hipFree(c->lowres);
+  if (c->zero_page) (void)hipFree(c->zero_page);
   if (c->owned_weights) (void)hipFree(c->owned_weights);
   for (auto& set : c->prof_sets) for (hipEvent_t ev : set) (void)hipEventDestroy(ev);
   delete c;
@@ -291,6 +299,15 @@ int nbc_load_weights(nbc_ctx* c, const nbc_tensor* tensors, int n, int precision
 int nbc_set_normalization(nbc_ctx* c, const float mean[3], const float stdv[3]) {
   if (!c || !mean || !stdv) return set_error(NBC_ERR_INVALID, "nbc_set_normalization: null argument");
   for (int i = 0; i < 3; ++i) { c->mean[i] = mean[i]; c->stdv[i] = stdv[i]; }
+  return NBC_OK;
+}
+
+int nbc_set_conv_impl(nbc_ctx* c, int impl, int tile) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  if (impl != 0 && impl != 1) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: impl must be 0 or 1");
+  if (tile < -1 || tile >= CONV_TILE_COUNT) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: bad tile id");
+  c->conv_impl = impl;
+  c->conv_tile = tile;
   return NBC_OK;
 }
 
@@ -384,7 +401,14 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         a.relu = u.relu ? 1 : 0;
         a.stem = pc.stem ? 1 : 0;
         if (o.Ci != pc.cin_pad) return set_error(NBC_ERR_STATE, "plan/channel mismatch at " + o.name);
-        e = launch_conv_igemm(a, prec, s);
+        a.zero = c->zero_page;
+        if (c->conv_impl == 0) {
+          e = launch_conv_igemm(a, prec, s);
+        } else {
+          int tile = c->conv_tile;
+          if (tile >= 0 && o.Co % conv_tile_cols(tile) != 0) tile = -1;   // override does not fit this layer
+          e = launch_conv_dma(a, prec, tile, s);
+        }
         break;
       }
       case OP_MAXPOOL:

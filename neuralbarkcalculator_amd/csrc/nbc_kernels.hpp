@@ -15,7 +15,8 @@ struct ConvArgs {
   const float* shift;   // [Co]
   const void* res;      // nullable, [M][Co] elements (the identity of a bottleneck)
   void* y;              // [M][Co] elements
-  unsigned x_bytes;     // size of x in bytes (< 2 GiB): buffer range check = zero fill of the halo
+  const void* zero;     // >= 16 zero bytes in device memory: DMA source of halo / tail lanes (v2)
+  unsigned x_bytes;     // size of x in bytes (< 2 GiB): buffer range check = zero fill of the halo (v1)
   unsigned w_bytes;     // size of w in bytes
   int N, Hi, Wi, Ci;
   int Ho, Wo, Co;
@@ -27,7 +28,15 @@ struct ConvArgs {
 };
 
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_32x32x16_bf16)
+// v1: register-staged, 128 x {64,128} tiles (conv_igemm.hip); kept as the A/B reference kernel.
 hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
+
+// v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co).
+enum { CONV_TILE_128x64 = 0, CONV_TILE_128x128 = 1, CONV_TILE_256x128 = 2, CONV_TILE_256x256 = 3, CONV_TILE_COUNT = 4 };
+int conv_tile_rows(int tile);
+int conv_tile_cols(int tile);
+int choose_conv_tile(int M, int Co);
+hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
 
 // float32 NCHW [N,3,H,W] -> NHWC elements padded to 16 bytes per pixel.
 hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int precision, hipStream_t s);

@@ -229,6 +229,11 @@ class FCNResNet50:
                             k=int(rec.kh), cout=int(rec.cout)))
         return out
 
+    def set_conv_impl(self, impl: int = 1, tile: int = -1):
+        """Tuning/test knob: impl 1 = LDS-DMA ring kernel, 0 = register-staged kernel; tile -1 = auto,
+        0..3 = 128x64 / 128x128 / 256x128 / 256x256."""
+        _lib.check(self._lib.nbc_set_conv_impl(self._require_ctx(), int(impl), int(tile)), "nbc_set_conv_impl")
+
     def set_keep_activations(self, on: bool):
         _lib.check(self._lib.nbc_set_keep_activations(self._require_ctx(), int(on)))
 

@@ -1,0 +1,230 @@
+"""Folder-level batch prediction: the caller side of the hot path, sharded over the GPUs of a node.
+
+Reproduces the file contract of the reference's inference entry point
+(/root/reference/src/bark_calculator/predict.py:10-58 and models.py:230-364) around the
+accelerated model call:
+
+* input  ``ROOT/samples/<wood_type>/*.{bmp,png,...}``; wood types and order of ``dataset.py:50-58``
+  (``epinette_gelee, epinette_non_gelee, sapin``; file names sorted; ``"bmp" -> "png"`` in the
+  output name, every occurrence, like ``str.replace`` there);
+* ``ROOT/processed/samples/<wood_type>/<name>.png`` (``models.py:173-203``; the 4096->1024 spline
+  resize is NOT built -- SURVEY.md row N4 -- so images larger than 1024 raise; ``trim_black`` is);
+* ``ROOT/results/outputs/<wood_type>/<name>.png``: uint8 {0,127,255} mode 'L' (``models.py:349-356``);
+* ``ROOT/results/final_stats.csv``: tab separated, the reference's 7-name header and 6-value rows
+  (``models.py:252-255,315-332,360-364``: ``img_size`` is dropped by the re-initialisation at
+  ``models.py:321``; reproduced verbatim).  The matplotlib figure of ``models.py:280-347``
+  (about 10 s per image) is not produced.
+
+Multi-GPU (one process per GPU, ``torch.distributed`` over RCCL): rank r takes images
+``r, r+W, ...`` of the sorted list; rank 0 alone reads the checkpoint and broadcasts the packed
+weights; every rank fills int64 rows ``(global_idx, H, W, count_1, count_2)`` which one
+``all_gather`` brings to rank 0 for the CSV.  No collective sits in the per-image path.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import os
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+WOOD_TYPES = ["epinette_gelee", "epinette_non_gelee", "sapin"]            # dataset.py:50
+IMG_EXTENSIONS = [".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", "webp"]  # dataset.py:77-79
+MM2_PER_PIXEL = 3.6 * 3.6                                                  # models.py:210
+CSV_HEADER = ["Name", "Type", "Image Size", "Output Bark %", "Bark area (mm^2)",
+              "Output Node %", "Node area (mm^2)"]                         # models.py:252-255
+ROW_WIDTH = 5                                                              # (global_idx, H, W, count_1, count_2)
+
+
+def generate_folders(root: str, only_preprocess: bool = False) -> None:
+    """predict.py:10-48."""
+    present = os.listdir(os.path.join(root, "samples"))
+    wood_types = [w for w in WOOD_TYPES if w in present]
+    for w in wood_types:
+        os.makedirs(os.path.join(root, "processed", "samples", w), exist_ok=True)
+    if not only_preprocess:
+        for level in ("combined_images", "outputs"):
+            for w in wood_types:
+                os.makedirs(os.path.join(root, "results", level, w), exist_ok=True)
+
+
+def list_images(dir_: str) -> List[Tuple[str, str, str]]:
+    """(sample_path, output_name, wood_type) in the order of dataset.py:41-68."""
+    samples = os.path.join(dir_, "samples")
+    if not os.path.isdir(samples):
+        raise IOError("Root folder should have a 'samples' subfolder !")   # dataset.py:45-46
+    out = []
+    for wood in WOOD_TYPES:
+        d = os.path.join(samples, wood)
+        for _, _, fnames in sorted(os.walk(d)):
+            for fname in sorted(fnames):
+                if any(fname.lower().endswith(e) for e in IMG_EXTENSIONS):
+                    out.append((os.path.join(d, fname), fname.replace("bmp", "png"), wood))
+    return out
+
+
+def trim_black(image: np.ndarray) -> np.ndarray:
+    """models.py:157-166 on a float HWC image in [0,1]: drop leading/trailing rows in which 15 % or
+    more of the pixels are black (channel sum <= 1e-3)."""
+    lit = np.sum(image, axis=-1) > 1e-3
+    clear = np.mean(lit, axis=-1) > 0.85
+    first = int(np.argmax(clear))
+    last = image.shape[0] - int(np.argmax(clear[::-1]))
+    return image[first:last]
+
+
+def preprocess_images(root: str, target_size: int = 1024) -> None:
+    """models.py:173-203 without the spline resize (row N4): RGB decode, trim_black on square
+    images, save as PNG under processed/."""
+    from PIL import Image
+    for path, name, wood in list_images(root):
+        with open(path, "rb") as f:
+            img = np.asarray(Image.open(f).convert("RGB"))                 # dataset.py:82-90
+        if max(img.shape[:2]) > target_size:
+            raise NotImplementedError(
+                f"{path}: {img.shape[1]}x{img.shape[0]} needs the 4096->1024 resize of models.py:194-198, "
+                "which is outside the accelerated path (SURVEY.md N4); resize it first")
+        if img.shape[0] == img.shape[1]:
+            img = (trim_black(img.astype(np.float32) / 255.0) * 255.0 + 0.5).astype(np.uint8)
+        Image.fromarray(img, mode="RGB").save(os.path.join(root, "processed", "samples", wood, name))
+
+
+def shard_indices(n: int, rank: int, world: int) -> List[int]:
+    """Images of rank ``rank``: r, r+W, r+2W, ...."""
+    return list(range(rank, n, world))
+
+
+def stats_row(name: str, wood: str, h: int, w: int, count_1: int, count_2: int) -> List[str]:
+    """One CSV row, float32 arithmetic and '{:.5f}' formatting of models.py:321-332."""
+    row = [name, wood]
+    pixels = np.float32(h * w)
+    for c in (count_1, count_2):
+        frac = np.float32(c) / pixels                 # (outputs == c).float().mean(): exact sum / N in f32
+        row.append("{:.5f}".format(float(frac * np.float32(100))))
+        row.append("{:.5f}".format(float(np.float32(c) * np.float32(MM2_PER_PIXEL))))
+    return row
+
+
+def write_stats_csv(path: str, rows: Sequence[Sequence[str]]) -> None:
+    with open(path, "w") as f:                       # models.py:360-364 (no newline='' there either)
+        csv.writer(f, delimiter="\t").writerows([CSV_HEADER] + [list(r) for r in rows])
+
+
+def label_png(labels: np.ndarray) -> np.ndarray:
+    """models.py:349-353: uint8 map with Bark = 127, Node = 255."""
+    out = np.zeros(labels.shape, dtype=np.uint8)
+    out[labels == 1] = 127
+    out[labels == 2] = 255
+    return out
+
+
+def gather_rows(local_rows: np.ndarray, n_total: int, world: int, dist=None, device=None) -> np.ndarray:
+    """all_gather of fixed-size per-rank row buffers; returns the rows sorted by global index.
+    ``local_rows``: int64 [k, ROW_WIDTH] with k <= ceil(n_total / world)."""
+    import torch
+    cap = (n_total + world - 1) // world if n_total else 0
+    buf = torch.full((max(cap, 1), ROW_WIDTH), -1, dtype=torch.int64)
+    if len(local_rows):
+        buf[: len(local_rows)] = torch.from_numpy(np.asarray(local_rows, dtype=np.int64))
+    if dist is None or world == 1:
+        allrows = buf
+    else:
+        if device is not None:
+            buf = buf.to(device)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        allrows = torch.cat(parts).cpu()
+    allrows = allrows.numpy()
+    allrows = allrows[allrows[:, 0] >= 0]
+    return allrows[np.argsort(allrows[:, 0], kind="stable")]
+
+
+def predict_folder(root: str, model_path: str = "./best_model.pt", precision: str = "fp32",
+                   exclude_nodes: bool = False, small_zones: bool = True, device_index: int = None) -> None:
+    """predict.py:51-58 + models.py:230-364 with the model call on the MI355X path."""
+    import torch
+    from PIL import Image
+    from .model import FCNResNet50
+    from .postprocess import remove_small_zones
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if device_index is None else device_index
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    if rank == 0:
+        generate_folders(root)
+        preprocess_images(root)
+    if dist is not None:
+        dist.barrier()
+
+    model = FCNResNet50(precision)
+    if rank == 0:                                    # only one rank touches the checkpoint
+        model.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True))
+    model.to(dev)
+    if dist is not None:
+        model.broadcast_weights(src=0)
+
+    images = list_images(os.path.join(root, "processed"))
+    mine = shard_indices(len(images), rank, world)
+    rows = np.zeros((len(mine), ROW_WIDTH), dtype=np.int64)
+    for k, gi in enumerate(mine):
+        path, name, wood = images[gi]
+        with open(path, "rb") as f:
+            img = np.ascontiguousarray(np.asarray(Image.open(f).convert("RGB")))
+        x = torch.from_numpy(img)[None].to(dev)                      # uint8 NHWC; normalised on device
+        labels, counts = model.predict_labels(x, exclude_nodes=False, labels_dtype=torch.uint8)
+        lab = labels[0].cpu().numpy()
+        if small_zones:                                              # models.py:271
+            lab = remove_small_zones(lab)
+        if exclude_nodes:                                            # models.py:273-276
+            lab[lab == 2] = 1
+        if small_zones or exclude_nodes:
+            c1, c2 = int((lab == 1).sum()), int((lab == 2).sum())
+        else:
+            c1, c2 = int(counts[0, 1]), int(counts[0, 2])
+        rows[k] = (gi, lab.shape[0], lab.shape[1], c1, c2)
+        Image.fromarray(label_png(lab), mode="L").save(os.path.join(root, "results", "outputs", wood, name))
+
+    allrows = gather_rows(rows, len(images), world, dist, dev)
+    if rank == 0:
+        write_stats_csv(os.path.join(root, "results", "final_stats.csv"),
+                        [stats_row(images[int(r[0])][1], images[int(r[0])][2], int(r[1]), int(r[2]), int(r[3]), int(r[4]))
+                         for r in allrows])
+    if dist is not None:
+        dist.barrier()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="MI355X folder prediction (mirrors bark_calculator/predict.py)")
+    ap.add_argument("root_path", metavar="DIR")
+    ap.add_argument("--device", default="cuda:0", help="cuda:N (the CPU path is the reference itself)")
+    ap.add_argument("--exclude_nodes", action="store_true")
+    ap.add_argument("--only_preprocess", action="store_true")
+    ap.add_argument("--model_path", default="./best_model.pt")       # predict.py:57
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--no_small_zones", action="store_true")
+    args = ap.parse_args(argv)
+    if args.only_preprocess:
+        generate_folders(args.root_path, True)
+        preprocess_images(args.root_path)
+        return
+    if not args.device.startswith("cuda"):
+        raise SystemExit("this package is the MI355X path; run the reference for --device=cpu")
+    idx = None
+    if "WORLD_SIZE" not in os.environ and ":" in args.device:
+        idx = int(args.device.split(":")[1])
+    predict_folder(args.root_path, args.model_path, args.precision, args.exclude_nodes,
+                   not args.no_small_zones, idx)
+
+
+if __name__ == "__main__":
+    main()

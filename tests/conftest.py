@@ -35,7 +35,8 @@ def sd_np():
 @pytest.fixture(scope="session")
 def oracle_model(sd_np):
     from oracle.fcn_resnet50_oracle import OracleFCNResNet50
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box reports 256 CPUs but grants a 16-core share: oversubscribing makes the oracle crawl
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 8))
     m = OracleFCNResNet50()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     return m

@@ -248,3 +248,29 @@ def test_errors_are_python_exceptions(gpu_fp32):
         gpu_fp32(torch.zeros(1, 3, 16, 16))                    # wrong device
     with pytest.raises(RuntimeError):
         FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
+
+
+@pytest.mark.parametrize("impl,tile", [(0, -1), (1, 0), (1, 1), (1, 2), (1, 3)])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, impl, tile):
+    """Each conv kernel instantiation (register-staged v1; LDS-DMA v2 at every tile shape) against
+    the oracle, layer by layer, on an input whose height is not a multiple of the tile rows."""
+    from oracle.fcn_resnet50_oracle import layer_outputs
+    model = gpu_fp32 if mode == "fp32" else gpu_bf16
+    rtol = LAYER_RTOL_FP32 if mode == "fp32" else LAYER_RTOL_BF16
+    x = frames([9], 104, 136)
+    ref = layer_outputs(oracle_model, x)
+    model.set_conv_impl(impl, tile)
+    model.set_keep_activations(True)
+    try:
+        lowres = model.lowres_logits(x.to(DEV))
+        torch.cuda.synchronize()
+        for name, want in ref.items():
+            got = lowres.cpu().numpy() if name == "classifier.4" else model.read_activation(name, want.numel())
+            want = want.numpy()
+            scale = float(np.abs(want).max())
+            err = float(np.abs(got - want).max())
+            assert err <= rtol * scale, f"{name}: max err {err} vs scale {scale} ({mode}, impl {impl}, tile {tile})"
+    finally:
+        model.set_keep_activations(False)
+        model.set_conv_impl(1, -1)
