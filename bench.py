@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
     ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0..3 force a tile shape (A/B runs)")
+    ap.add_argument("--dump-ops", default=None, help="write the per-launch records (JSON) to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-op-events", action="store_true", help="timed region without per-launch HIP events")
@@ -184,6 +185,9 @@ def main():
         "setup_s": t_setup,
     }
 
+    if records and args.dump_ops:
+        with open(args.dump_ops, "w") as f:
+            json.dump(records, f, indent=1)
     if records:
         conv = [r for r in records if r["kernel"] == "conv_igemm"]
         dom = [r for r in conv if r["cout"] % 128 == 0 and r["name"] != "backbone.conv1"]   # wide-tile instantiation

@@ -236,50 +236,88 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     compute(t % S);
   }
 
-  // ---- epilogue (all DMAs retired by the last wait)
+  // ---- epilogue (all DMAs retired by the last wait).
+  // The accumulators hold, per lane, one pixel and groups of four channels: stored as they stand,
+  // a wave would touch 32 pixel rows with 16 bytes each per instruction (measured: the residual
+  // 1x1 convs ran at ~2 TB/s).  Instead each wave transposes one 32-pixel x (NT*32)-channel slab at
+  // a time through a private f32 scratch in the (now idle) LDS ring: BN scale/shift is applied on
+  // the way in, and on the way out every lane owns 16 output bytes of one pixel, so identity loads
+  // and stores are whole 128-byte (bf16) / 256-byte (f32) row segments.
+  constexpr int SLAB_CH = NT * 32;                  // channels of the wave's slab
+  constexpr int PITCH = SLAB_CH * 4 + 16;           // f32 scratch row, padded against bank conflicts
+  constexpr int OUT_CH = 16 / EB;                   // channels per 16 output bytes
+  constexpr int CPR = SLAB_CH / OUT_CH;             // 16-byte output chunks per pixel row
+  constexpr int PIX_PER_PASS = 64 / CPR;
+  constexpr int PASSES = 32 / PIX_PER_PASS;
+  static_assert(WM * WN * 32 * PITCH <= S * STAGE_BYTES, "epilogue scratch must fit in the ring");
+  __syncthreads();                                  // every wave has finished reading the ring
+  unsigned char* scr = smem + wave * (32 * PITCH);
   unsigned char* yb = static_cast<unsigned char*>(p.y);
   const unsigned char* resb = static_cast<const unsigned char*>(p.res);
+  const int o_pix = lane / CPR, o_chunk = lane % CPR;
+  const int n_slab = n0 + wn * SLAB_CH;
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + (wm * MT + i) * 32 + r;
-      if (m >= p.M) continue;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + (wn * NT + j) * 32 + 8 * g + 4 * h;
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
-        float v[4];
-        v[0] = __builtin_fmaf(acc[j][i][4 * g + 0], sc.x, sh.x);
-        v[1] = __builtin_fmaf(acc[j][i][4 * g + 1], sc.y, sh.y);
-        v[2] = __builtin_fmaf(acc[j][i][4 * g + 2], sc.z, sh.z);
-        v[3] = __builtin_fmaf(acc[j][i][4 * g + 3], sc.w, sh.w);
-        const size_t eoff = ((size_t)m * p.Co + n) * EB;
+        const int nl = j * 32 + 8 * g + 4 * h;      // channel inside the slab
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n_slab + nl);
+        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n_slab + nl);
+        float4 v;
+        v.x = __builtin_fmaf(acc[j][i][4 * g + 0], sc.x, sh.x);
+        v.y = __builtin_fmaf(acc[j][i][4 * g + 1], sc.y, sh.y);
+        v.z = __builtin_fmaf(acc[j][i][4 * g + 2], sc.z, sh.z);
+        v.w = __builtin_fmaf(acc[j][i][4 * g + 3], sc.w, sh.w);
+        *reinterpret_cast<float4*>(scr + r * PITCH + nl * 4) = v;
+      }
+    // the scratch is wave-private: LDS operations of one wave complete in order
+#pragma unroll
+    for (int ps2 = 0; ps2 < PASSES; ++ps2) {
+      const int pix = ps2 * PIX_PER_PASS + o_pix;
+      const int m = m0 + (wm * MT + i) * 32 + pix;
+      float v[OUT_CH];
+      const float4* sp = reinterpret_cast<const float4*>(scr + pix * PITCH + o_chunk * OUT_CH * 4);
+#pragma unroll
+      for (int q = 0; q < OUT_CH / 4; ++q) {
+        const float4 t4 = sp[q];
+        v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+      }
+      if (m < p.M) {
+        const size_t eoff = ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB;
         if (resb) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(resb + eoff);
           if constexpr (PREC == 0) {
-            const float4 rv = *reinterpret_cast<const float4*>(resb + eoff);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            v[0] += __builtin_bit_cast(float, rv.x); v[1] += __builtin_bit_cast(float, rv.y);
+            v[2] += __builtin_bit_cast(float, rv.z); v[3] += __builtin_bit_cast(float, rv.w);
           } else {
-            const ushort4 rv = *reinterpret_cast<const ushort4*>(resb + eoff);
-            v[0] += bf16_bits_to_f32(rv.x); v[1] += bf16_bits_to_f32(rv.y);
-            v[2] += bf16_bits_to_f32(rv.z); v[3] += bf16_bits_to_f32(rv.w);
+            const unsigned u[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[2 * q] += __builtin_bit_cast(float, u[q] << 16);
+              v[2 * q + 1] += __builtin_bit_cast(float, u[q] & 0xffff0000u);
+            }
           }
         }
         if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : (v[e] != v[e] ? v[e] : 0.f);
+          for (int e = 0; e < OUT_CH; ++e) v[e] = v[e] > 0.f ? v[e] : (v[e] != v[e] ? v[e] : 0.f);
         }
+        uint4 o;
         if constexpr (PREC == 0) {
-          *reinterpret_cast<float4*>(yb + eoff) = make_float4(v[0], v[1], v[2], v[3]);
+          o.x = __builtin_bit_cast(unsigned, v[0]); o.y = __builtin_bit_cast(unsigned, v[1]);
+          o.z = __builtin_bit_cast(unsigned, v[2]); o.w = __builtin_bit_cast(unsigned, v[3]);
         } else {
-          ushort4 o;
-          o.x = f32_to_bf16_bits(v[0]); o.y = f32_to_bf16_bits(v[1]);
-          o.z = f32_to_bf16_bits(v[2]); o.w = f32_to_bf16_bits(v[3]);
-          *reinterpret_cast<ushort4*>(yb + eoff) = o;
+          o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+          o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+          o.z = (unsigned)f32_to_bf16_bits(v[4 % OUT_CH]) | ((unsigned)f32_to_bf16_bits(v[5 % OUT_CH]) << 16);
+          o.w = (unsigned)f32_to_bf16_bits(v[6 % OUT_CH]) | ((unsigned)f32_to_bf16_bits(v[7 % OUT_CH]) << 16);
         }
+        *reinterpret_cast<uint4*>(yb + eoff) = o;
       }
     }
+  }
 }
 
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>

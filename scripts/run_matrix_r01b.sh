@@ -1,0 +1,7 @@
+source scripts/bench_matrix.sh true
+run bf16_auto --steps 50 --warmup 5
+run bf16_t1 --steps 30 --warmup 3 --conv-tile 1
+run bf16_t2 --steps 30 --warmup 3 --conv-tile 2
+run fp32_auto --steps 20 --warmup 3 --precision fp32
+run bf16_b8 --steps 10 --warmup 2 --batch 8
+run bf16_noev --steps 50 --warmup 5 --no-op-events
