@@ -20,6 +20,8 @@
 //
 // D[n][m] orientation as in v1: weights are the MFMA A operand, pixels the B operand, so a lane
 // ends up holding one pixel (column) and groups of four consecutive output channels (rows).
+#include <cstdlib>
+
 #include "nbc_kernels.hpp"
 
 namespace nbc {
@@ -61,7 +63,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // Tile = (WM*MT*32) pixels x (WN*NT*32) channels, WM*WN waves, S LDS stages.
-template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EB = PREC == 0 ? 4 : 2;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       }
     }
   }
-  const unsigned char* wsrc[B_PASSES];
+  const unsigned char* wsrc[B_PASSES];       // advances by one K-step (128 B) per issue
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
     const int row = lr + ROWS_PER_PASS * i;
@@ -139,27 +141,41 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   const unsigned smem_base = (unsigned)(size_t)(lds_u8*)smem;     // LDS byte offset of the ring
   const unsigned wave_off = (unsigned)wave * 1024u;
-  const int cblocks = STEM ? 1 : pix_bytes / 128;
+  const int cblocks = STEM ? 1 : pix_bytes / 128;                 // K-steps per tap
   int ld_kh = 0, ld_kw = 0, ld_cb = 0;
+
+  // Source pointers of the activation rows for the CURRENT tap.  Inside a tap a K-step only moves
+  // 128 bytes along the channels, so the per-step work is one pointer add per row; the bounds test
+  // and the address arithmetic run once per tap (once per kernel for a 1x1 convolution).  Halo and
+  // tail rows point at the zero page and do not advance.
+  const unsigned char* a_ptr[A_PASSES];
+  int a_inc[A_PASSES];
+  auto set_tap = [&](int kh, int kw) {
+    const int dy = kh * p.dil, dx = kw * p.dil;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * pix_bytes + a_coff[i];
+      a_ptr[i] = ok ? xb + off : zpage;
+      a_inc[i] = ok ? 128 : 0;
+    }
+  };
+  if constexpr (!STEM) set_tap(0, 0);
 
   auto issue_step = [&](int t, int stage) {
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
     const unsigned sb = sa + A_BYTES;
     if constexpr (!STEM) {
-      const int dy = ld_kh * p.dil, dx = ld_kw * p.dil;
-      const int cbo = ld_cb * 128;
 #pragma unroll
       for (int i = 0; i < A_PASSES; ++i) {
-        const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-        const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * pix_bytes + (cbo + a_coff[i]);
-        // arithmetic select keeps the DMA unconditional: halo / tail lanes copy 16 zero bytes
-        const unsigned char* src = ok ? xb + off : zpage;
-        dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
+        dma16(a_ptr[i], sa + (unsigned)(ROWS_PER_PASS * 128 * i));
+        a_ptr[i] += a_inc[i];
       }
-      if (++ld_cb == cblocks) {
+      if (++ld_cb == cblocks) {                    // wave-uniform: next K-step starts a new tap
         ld_cb = 0;
         if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+        if (ld_kh < p.KH) set_tap(ld_kh, ld_kw);
       }
     } else {
 #pragma unroll
@@ -174,8 +190,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       }
     }
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i)
-      dma16(wsrc[i] + (size_t)t * 128, sb + (unsigned)(ROWS_PER_PASS * 128 * i));
+    for (int i = 0; i < B_PASSES; ++i) {
+      dma16(wsrc[i], sb + (unsigned)(ROWS_PER_PASS * 128 * i));
+      wsrc[i] += 128;
+    }
   };
 
   // ---- MFMA geometry
@@ -189,35 +207,44 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
 
+  // Fragments are double-buffered in registers: the ds_read_b128 of chunk pair ks+1 are issued
+  // before the MFMAs of chunk pair ks, so LDS latency hides under the matrix pipe.
   auto compute = [&](int stage) {
     const unsigned char* sa = smem + stage * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    uint4 pf[2][MT], wf[2][NT];
+    auto load_frags = [&](int ks, uint4 (&pfr)[MT], uint4 (&wfr)[NT]) {
       const int chunk = 2 * ks + h;
-      uint4 pf[MT], wf[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        pf[i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * MT + i) * 32 + r, chunk));
+        pfr[i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * MT + i) * 32 + r, chunk));
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        wf[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
+        wfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
+    };
+    load_frags(0, pf[0], wf[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) load_frags(ks + 1, pf[(ks + 1) & 1], wf[(ks + 1) & 1]);
+      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           if constexpr (PREC == 1) {
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, wf[j]), __builtin_bit_cast(bf16x8, pf[i]), acc[j][i], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, wf[ks & 1][j]), __builtin_bit_cast(bf16x8, pf[ks & 1][i]),
+                acc[j][i], 0, 0, 0);
           } else {
-            const float4 wv = __builtin_bit_cast(float4, wf[j]);
-            const float4 pv = __builtin_bit_cast(float4, pf[i]);
+            const float4 wv = __builtin_bit_cast(float4, wf[ks & 1][j]);
+            const float4 pv = __builtin_bit_cast(float4, pf[ks & 1][i]);
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, pv.x, acc[j][i], 0, 0, 0);
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, pv.y, acc[j][i], 0, 0, 0);
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, pv.z, acc[j][i], 0, 0, 0);
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, acc[j][i], 0, 0, 0);
           }
         }
+      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
     }
   };
 
@@ -320,12 +347,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   }
 }
 
-template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int smem = S * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM>;
+  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -338,13 +365,13 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, bool STEM>
+template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
-    case CONV_TILE_128x64:  return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM>(a, s);   // 72 KiB LDS, 2 blocks/CU
-    case CONV_TILE_128x128: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM>(a, s);   // 64 KiB LDS, 2 blocks/CU
-    case CONV_TILE_256x128: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM>(a, s);   // 144 KiB LDS, 8 waves
-    case CONV_TILE_256x256: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM>(a, s);   // 128 KiB LDS, 8 waves
+    case CONV_TILE_128x64:  return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);   // 72 KiB LDS, 2 blocks/CU
+    case CONV_TILE_128x128: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);   // 64 KiB LDS, 2 blocks/CU
+    case CONV_TILE_256x128: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, VAR>(a, s);   // 144 KiB LDS, 8 waves
+    case CONV_TILE_256x256: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, VAR>(a, s);   // 128 KiB LDS, 8 waves
     default: return hipErrorInvalidValue;
   }
 }
@@ -381,8 +408,12 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   }
   if (tile < 0) tile = choose_conv_tile(a.M, a.Co);
   if (tile < 0 || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
-  if (precision == 0) return a.stem ? launch_tile<0, true>(a, tile, s) : launch_tile<0, false>(a, tile, s);
-  return a.stem ? launch_tile<1, true>(a, tile, s) : launch_tile<1, false>(a, tile, s);
+  // NBC_CONV_VARIANT=1 selects the experimental build with s_setprio around the MFMA clusters
+  static const int variant = [] { const char* e = getenv("NBC_CONV_VARIANT"); return e ? atoi(e) : 0; }();
+  if (variant == 1 && !a.stem)
+    return precision == 0 ? launch_tile<0, false, 1>(a, tile, s) : launch_tile<1, false, 1>(a, tile, s);
+  if (precision == 0) return a.stem ? launch_tile<0, true, 0>(a, tile, s) : launch_tile<0, false, 0>(a, tile, s);
+  return a.stem ? launch_tile<1, true, 0>(a, tile, s) : launch_tile<1, false, 0>(a, tile, s);
 }
 
 }  // namespace nbc

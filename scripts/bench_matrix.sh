@@ -6,7 +6,7 @@ run() { tag=$1; shift; timeout -k 10 240 python bench.py --no-cpu-baseline --no-
 import json
 d=json.load(open("gpurun_out/bench_$tag.json"))
 r=d.get("roofline",{})
-print("$tag", "img/s %.1f" % d["value"], "ms/step %.3f" % d["ms_per_step"], "conv TF %.0f" % r.get("achieved",0), "3x3 TF %.0f" % r.get("conv3x3_tflops",0), "sumk %.3f" % r.get("sum_kernel_ms_per_step",0))
+print("$tag", "img/s %.1f" % d["value"], "ms/step %.3f" % d["ms_per_step"], "instr %.3f" % r.get("instrumented_ms_per_step",0), "conv TF %.0f" % r.get("achieved",0), "3x3 TF %.0f" % r.get("conv3x3_tflops",0), "sumk %.3f" % r.get("sum_kernel_ms_per_step",0))
 PY
 }
 "$@"
