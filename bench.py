@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
     ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0..3 force a tile shape (A/B runs)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent batch-1 forwards kept in flight on separate HIP streams (each its own workspace)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch records (JSON) to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -126,6 +128,14 @@ def main():
         batches.append(torch.from_numpy(b).to(dev))
     model.reserve(args.batch, H, W)
     model.set_conv_impl(args.conv_impl, args.conv_tile)
+    nstreams = max(1, args.streams)
+    models = [model]
+    for _ in range(nstreams - 1):
+        m2 = model.clone_shared()
+        m2.reserve(args.batch, H, W)
+        m2.set_conv_impl(args.conv_impl, args.conv_tile)
+        models.append(m2)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup0
 
@@ -133,15 +143,17 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def step(i):
-        return model.predict_labels(batches[i % nf], labels_dtype=torch.uint8)
+    def step(i, k=None):
+        k = i % nstreams if k is None else k
+        with torch.cuda.stream(streams[k]):
+            return models[k].predict_labels(batches[i % nf], labels_dtype=torch.uint8)
 
-    def timed_region(n_steps):
+    def timed_region(n_steps, k=None):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            step(i)
+            step(i, k)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
@@ -162,7 +174,7 @@ def main():
     records, dt_events = [], None
     if not args.no_op_events:
         model.set_profiling(True)
-        dt_events = timed_region(args.steps)
+        dt_events = timed_region(args.steps, 0)      # one stream: clean per-launch durations
         records = model.op_records()
         model.set_profiling(False)
 
@@ -188,7 +200,7 @@ def main():
         "config": {"workload": "configs[1]: 1xMI355X per rank, batch=%d, %s fcn_resnet50 (eval), synthetic "
                                "1024x1024x3 frames resident in HBM, forward+argmax+class counts" % (args.batch, args.weights),
                    "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank",
-                   "conv_impl": args.conv_impl, "conv_tile": args.conv_tile},
+                   "conv_impl": args.conv_impl, "conv_tile": args.conv_tile, "streams": nstreams},
         "setup_s": t_setup,
     }
 

@@ -248,13 +248,28 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     }
   };
 
+  // ---- epilogue geometry (needed before the last K-step: the identity tile is prefetched there)
+  constexpr int SLAB_CH = NT * 32;                  // channels of the wave's slab
+  constexpr int PITCH = SLAB_CH * 4 + 16;           // f32 scratch row, padded against bank conflicts
+  constexpr int OUT_CH = 16 / EB;                   // channels per 16 output bytes
+  constexpr int CPR = SLAB_CH / OUT_CH;             // 16-byte output chunks per pixel row
+  constexpr int PIX_PER_PASS = 64 / CPR;
+  constexpr int PASSES = 32 / PIX_PER_PASS;
+  constexpr bool RES_PREFETCH = (MT * PASSES <= 16);   // <= 64 VGPRs of identity per lane
+  static_assert(WM * WN * 32 * PITCH <= S * STAGE_BYTES, "epilogue scratch must fit in the ring");
+  unsigned char* yb = static_cast<unsigned char*>(p.y);
+  const unsigned char* resb = static_cast<const unsigned char*>(p.res);
+  const int o_pix = lane / CPR, o_chunk = lane % CPR;
+  const int n_slab = n0 + wn * SLAB_CH;
+  uint4 rpre[RES_PREFETCH ? MT : 1][RES_PREFETCH ? PASSES : 1];
+
   // ---- pipeline.  Steps beyond T issue nothing; the counted wait then over-waits, which is safe
   // (vmcnt retires in order), and the tail uses vmcnt(0).
   const int T = p.ksteps;
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < T) issue_step(s, s);
-  for (int t = 0; t < T; ++t) {
+  for (int t = 0; t < T - 1; ++t) {
     // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
     if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
     else wait_vmcnt<0>();
@@ -262,27 +277,34 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
     compute(t % S);
   }
+  // last K-step, peeled: every DMA has retired, so the identity (residual) tile of the epilogue is
+  // requested here and its HBM/MALL latency hides under the last MFMAs and the transposes below.
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if constexpr (RES_PREFETCH) {
+    if (resb) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int ps2 = 0; ps2 < PASSES; ++ps2) {
+          int m = m0 + (wm * MT + i) * 32 + ps2 * PIX_PER_PASS + o_pix;
+          m = m < p.M ? m : p.M - 1;                 // tail rows read a valid row; never stored
+          rpre[i][ps2] = *reinterpret_cast<const uint4*>(
+              resb + ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB);
+        }
+    }
+  }
+  compute((T - 1) % S);
 
-  // ---- epilogue (all DMAs retired by the last wait).
+  // ---- epilogue.
   // The accumulators hold, per lane, one pixel and groups of four channels: stored as they stand,
   // a wave would touch 32 pixel rows with 16 bytes each per instruction (measured: the residual
   // 1x1 convs ran at ~2 TB/s).  Instead each wave transposes one 32-pixel x (NT*32)-channel slab at
   // a time through a private f32 scratch in the (now idle) LDS ring: BN scale/shift is applied on
   // the way in, and on the way out every lane owns 16 output bytes of one pixel, so identity loads
   // and stores are whole 128-byte (bf16) / 256-byte (f32) row segments.
-  constexpr int SLAB_CH = NT * 32;                  // channels of the wave's slab
-  constexpr int PITCH = SLAB_CH * 4 + 16;           // f32 scratch row, padded against bank conflicts
-  constexpr int OUT_CH = 16 / EB;                   // channels per 16 output bytes
-  constexpr int CPR = SLAB_CH / OUT_CH;             // 16-byte output chunks per pixel row
-  constexpr int PIX_PER_PASS = 64 / CPR;
-  constexpr int PASSES = 32 / PIX_PER_PASS;
-  static_assert(WM * WN * 32 * PITCH <= S * STAGE_BYTES, "epilogue scratch must fit in the ring");
   __syncthreads();                                  // every wave has finished reading the ring
   unsigned char* scr = smem + wave * (32 * PITCH);
-  unsigned char* yb = static_cast<unsigned char*>(p.y);
-  const unsigned char* resb = static_cast<const unsigned char*>(p.res);
-  const int o_pix = lane / CPR, o_chunk = lane % CPR;
-  const int n_slab = n0 + wn * SLAB_CH;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -314,7 +336,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       if (m < p.M) {
         const size_t eoff = ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB;
         if (resb) {
-          const uint4 rv = *reinterpret_cast<const uint4*>(resb + eoff);
+          uint4 rv;
+          if constexpr (RES_PREFETCH) rv = rpre[i][ps2];
+          else rv = *reinterpret_cast<const uint4*>(resb + eoff);
           if constexpr (PREC == 0) {
             v[0] += __builtin_bit_cast(float, rv.x); v[1] += __builtin_bit_cast(float, rv.y);
             v[2] += __builtin_bit_cast(float, rv.z); v[3] += __builtin_bit_cast(float, rv.w);

@@ -194,6 +194,16 @@ class FCNResNet50:
         with torch.cuda.device(self.device):
             _lib.check(self._lib.nbc_reserve(self._ctx, n, h, w), "nbc_reserve")
 
+    def clone_shared(self) -> "FCNResNet50":
+        """A second model object on the same device that shares this one's packed weights (one copy
+        in HBM) but owns its own context and activation workspace, so the two can run concurrently
+        on different HIP streams (pipelined batch-1 serving)."""
+        self._require_weights()
+        other = FCNResNet50(self.precision)
+        other.to(self.device)
+        other._attach(self._blob_dev)
+        return other
+
     # ---- multi-GPU: one process per GPU, weights read by one rank only ---------------------
     def broadcast_weights(self, src: int = 0, group=None):
         """RCCL broadcast of the packed weight blob from rank ``src`` (the only rank that needs
