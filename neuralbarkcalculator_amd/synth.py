@@ -141,7 +141,7 @@ def normalize_frame(img_u8: np.ndarray, mean=DEFAULT_MEAN, std=DEFAULT_STD) -> n
     x = img_u8.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
     m = np.asarray(mean, dtype=np.float32)[:, None, None]
     s = np.asarray(std, dtype=np.float32)[:, None, None]
-    return ((x - m) / s).astype(np.float32)
+    return np.ascontiguousarray(((x - m) / s).astype(np.float32))    # CHW in memory, like ToTensor
 
 
 def make_input(index: int, h: int = 1024, w: int = 1024) -> np.ndarray:
