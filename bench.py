@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
     ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0..3 force a tile shape (A/B runs)")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the default per-layer tile choice")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent batch-1 forwards kept in flight on separate HIP streams (each its own workspace)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch records (JSON) to this file")
@@ -128,12 +129,17 @@ def main():
         batches.append(torch.from_numpy(b).to(dev))
     model.reserve(args.batch, H, W)
     model.set_conv_impl(args.conv_impl, args.conv_tile)
+    tiles = None
+    if not args.no_autotune and args.conv_impl == 1 and args.conv_tile < 0:
+        tiles = model.autotune(batches[0])       # setup: per-layer tile shape by measurement
     nstreams = max(1, args.streams)
     models = [model]
     for _ in range(nstreams - 1):
         m2 = model.clone_shared()
         m2.reserve(args.batch, H, W)
         m2.set_conv_impl(args.conv_impl, args.conv_tile)
+        if tiles is not None:
+            m2.autotune(batches[0])
         models.append(m2)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
     torch.cuda.synchronize()
@@ -200,7 +206,8 @@ def main():
         "config": {"workload": "configs[1]: 1xMI355X per rank, batch=%d, %s fcn_resnet50 (eval), synthetic "
                                "1024x1024x3 frames resident in HBM, forward+argmax+class counts" % (args.batch, args.weights),
                    "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank",
-                   "conv_impl": args.conv_impl, "conv_tile": args.conv_tile, "streams": nstreams},
+                   "conv_impl": args.conv_impl, "conv_tile": args.conv_tile, "streams": nstreams,
+                   "autotuned_tiles": tiles},
         "setup_s": t_setup,
     }
 

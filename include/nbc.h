@@ -149,9 +149,19 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
                         int64_t* counts_dev, int exclude_nodes, void* hip_stream);
 
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
- * register-staged reference kernel; tile = -1 (per-layer choice) or 0..3 = 128x64, 128x128,
- * 256x128, 256x256 (pixels x channels) forced wherever the layer's Cout allows it. */
+ * register-staged reference kernel; tile = -1 (per-layer choice) or 0..6 = 128x64, 128x128,
+ * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64 (pixels x channels) forced wherever the
+ * layer's Cout allows it. */
 int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
+
+/* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real
+ * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the
+ * current (N,H,W) plan (`reps` launches each, HIP events) and keeps the fastest.  Results do not
+ * depend on the tile (same K order, one accumulator per output), only speed does.  The choice is
+ * part of the plan and is dropped when the plan is rebuilt for another (N,H,W).
+ * nbc_get_plan_tiles copies the tile id of each conv launch of the plan; returns their number. */
+int nbc_autotune(nbc_ctx* ctx, const void* x_dev, int x_dtype, int N, int H, int W, int reps, void* hip_stream);
+int nbc_get_plan_tiles(nbc_ctx* ctx, int32_t* tiles, int capacity);
 
 /* ---- debugging / measurement ----------------------------------------------------------- */
 /* Copy the activation written by conv unit `name` during the last forward to `dst_host` as

@@ -371,12 +371,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   }
 }
 
-template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int smem = S * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
+  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, 0>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -389,28 +389,42 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <int PREC, bool STEM, int VAR>
+// The tile menu.  rows x cols = pixels x channels; "blocks/CU" is what the LDS ring allows.
+//   id  tile      waves (m x n)  wave tile  stages  LDS      blocks/CU
+//   0   128x64    2x2            64x32      3       72 KiB   2
+//   1   128x128   2x2            64x64      2       64 KiB   2
+//   2   256x128   4x2            64x64      3       144 KiB  1
+//   3   256x256   2x4            128x64     2       128 KiB  1
+//   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch)
+//   5   128x256   2x4            64x64      3       144 KiB  1
+//   6   256x64    4x2            64x32      3       120 KiB  1
+template <int PREC, bool STEM>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
-    case CONV_TILE_128x64:  return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);   // 72 KiB LDS, 2 blocks/CU
-    case CONV_TILE_128x128: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);   // 64 KiB LDS, 2 blocks/CU
-    case CONV_TILE_256x128: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, VAR>(a, s);   // 144 KiB LDS, 8 waves
-    case CONV_TILE_256x256: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, VAR>(a, s);   // 128 KiB LDS, 8 waves
+    case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM>(a, s);
+    case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM>(a, s);
+    case 2: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM>(a, s);
+    case 3: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM>(a, s);
+    case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM>(a, s);
+    case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM>(a, s);
+    case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64};
+
 }  // namespace
 
-int conv_tile_rows(int tile) { return tile == CONV_TILE_128x64 || tile == CONV_TILE_128x128 ? 128 : 256; }
-int conv_tile_cols(int tile) {
-  return tile == CONV_TILE_128x64 ? 64 : (tile == CONV_TILE_256x256 ? 256 : 128);
-}
+int conv_tile_rows(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTileRows[tile] : 0; }
+int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTileCols[tile] : 0; }
 
-// Tile choice: the largest tile that still yields at least one tile per CU (256); when no shape
-// does, the one with the most tiles.  Bigger tiles move fewer L2->LDS bytes per FLOP.
+// Default tile (before nbc_autotune measures): the largest tile that still yields at least one
+// tile per CU (256); when no shape does, the one with the most tiles.  Bigger tiles move fewer
+// L2->LDS bytes per FLOP.
 int choose_conv_tile(int M, int Co) {
-  const int order[4] = {CONV_TILE_256x256, CONV_TILE_256x128, CONV_TILE_128x128, CONV_TILE_128x64};
+  const int order[4] = {3, 2, 1, 0};
   int best = -1, best_tiles = -1;
   for (int k = 0; k < 4; ++k) {
     const int t = order[k];
@@ -431,13 +445,9 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
     if ((a.Ci * eb) % 128 != 0 || a.ksteps != a.KH * a.KW * (a.Ci * eb / 128)) return hipErrorInvalidValue;
   }
   if (tile < 0) tile = choose_conv_tile(a.M, a.Co);
-  if (tile < 0 || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
-  // NBC_CONV_VARIANT=1 selects the experimental build with s_setprio around the MFMA clusters
-  static const int variant = [] { const char* e = getenv("NBC_CONV_VARIANT"); return e ? atoi(e) : 0; }();
-  if (variant == 1 && !a.stem)
-    return precision == 0 ? launch_tile<0, false, 1>(a, tile, s) : launch_tile<1, false, 1>(a, tile, s);
-  if (precision == 0) return a.stem ? launch_tile<0, true, 0>(a, tile, s) : launch_tile<0, false, 0>(a, tile, s);
-  return a.stem ? launch_tile<1, true, 0>(a, tile, s) : launch_tile<1, false, 0>(a, tile, s);
+  if (tile < 0 || tile >= CONV_TILE_COUNT || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
+  if (precision == 0) return a.stem ? launch_tile<0, true>(a, tile, s) : launch_tile<0, false>(a, tile, s);
+  return a.stem ? launch_tile<1, true>(a, tile, s) : launch_tile<1, false>(a, tile, s);
 }
 
 }  // namespace nbc

@@ -36,6 +36,7 @@ struct Op {
   int Hi, Wi, Ci, Ho, Wo, Co;
   std::string name;
   double flops, bytes;
+  int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
 };
 
 struct Plan {
@@ -118,6 +119,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
     o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
+    o.tile = choose_conv_tile(N * Ho * Wo, u.cout);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
     o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +
@@ -209,6 +211,38 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
   c->act_of.clear();
   for (size_t i = 0; i < P.ops.size(); ++i) c->act_of[P.ops[i].name] = (int)i;
   c->plan = P;
+  return NBC_OK;
+}
+
+// One convolution launch of the plan (shared by nbc_forward and nbc_autotune).
+int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream_t s, hipError_t* err) {
+  const auto& units = conv_units();
+  const ConvUnit& u = units[o.unit];
+  const PackedConv& pc = c->layout.convs[o.unit];
+  const int prec = c->precision;
+  ConvArgs a{};
+  a.x = c->bufs[o.in_buf];
+  a.w = c->weights + pc.w_off;
+  a.scale = reinterpret_cast<const float*>(c->weights + pc.scale_off);
+  a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
+  a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
+  a.y = c->bufs[o.out_buf];
+  a.zero = c->zero_page;
+  a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
+  a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
+  a.KH = u.k; a.KW = u.k; a.stride = u.stride; a.pad = u.pad; a.dil = u.dil;
+  a.M = N * o.Ho * o.Wo;
+  a.ksteps = pc.ksteps;
+  a.relu = u.relu ? 1 : 0;
+  a.stem = pc.stem ? 1 : 0;
+  if (o.Ci != pc.cin_pad) return set_error(NBC_ERR_STATE, "plan/channel mismatch at " + o.name);
+  const size_t xb = (size_t)N * o.Hi * o.Wi * o.Ci * elem_bytes(prec);
+  const size_t wbts = (size_t)o.Co * pc.ksteps * kKStepBytes;
+  if (xb >= 0x80000000ull || wbts >= 0x80000000ull)
+    return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
+  a.x_bytes = (unsigned)xb;
+  a.w_bytes = (unsigned)wbts;
+  *err = impl == 0 ? launch_conv_igemm(a, prec, s) : launch_conv_dma(a, prec, tile, s);
   return NBC_OK;
 }
 
@@ -345,7 +379,6 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
   if (rc != NBC_OK) return rc;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const Plan& P = c->plan;
-  const auto& units = conv_units();
   const int prec = c->precision;
 
   const size_t nops = P.ops.size();
@@ -368,6 +401,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
   for (size_t i = 0; i < nops; ++i) {
     const Op& o = P.ops[i];
     hipError_t e = hipSuccess;
+    int rc = NBC_OK;
     switch (o.kind) {
       case OP_INGEST:
         if (x_dtype == NBC_IN_F32_NCHW)
@@ -376,39 +410,10 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
           e = launch_ingest_u8(static_cast<const uint8_t*>(x_dev), c->bufs[o.out_buf], N, H, W, c->mean, c->stdv, prec, s);
         break;
       case OP_CONV: {
-        const ConvUnit& u = units[o.unit];
-        const PackedConv& pc = c->layout.convs[o.unit];
-        ConvArgs a{};
-        a.x = c->bufs[o.in_buf];
-        a.w = c->weights + pc.w_off;
-        a.scale = reinterpret_cast<const float*>(c->weights + pc.scale_off);
-        a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
-        a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
-        a.y = c->bufs[o.out_buf];
-        {
-          const size_t xb = (size_t)N * o.Hi * o.Wi * o.Ci * elem_bytes(prec);
-          const size_t wbts = (size_t)o.Co * pc.ksteps * kKStepBytes;
-          if (xb >= 0x80000000ull || wbts >= 0x80000000ull)
-            return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
-          a.x_bytes = (unsigned)xb;
-          a.w_bytes = (unsigned)wbts;
-        }
-        a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
-        a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
-        a.KH = u.k; a.KW = u.k; a.stride = u.stride; a.pad = u.pad; a.dil = u.dil;
-        a.M = N * o.Ho * o.Wo;
-        a.ksteps = pc.ksteps;
-        a.relu = u.relu ? 1 : 0;
-        a.stem = pc.stem ? 1 : 0;
-        if (o.Ci != pc.cin_pad) return set_error(NBC_ERR_STATE, "plan/channel mismatch at " + o.name);
-        a.zero = c->zero_page;
-        if (c->conv_impl == 0) {
-          e = launch_conv_igemm(a, prec, s);
-        } else {
-          int tile = c->conv_tile;
-          if (tile >= 0 && o.Co % conv_tile_cols(tile) != 0) tile = -1;   // override does not fit this layer
-          e = launch_conv_dma(a, prec, tile, s);
-        }
+        int tile = c->conv_tile;
+        if (tile < 0 || o.Co % conv_tile_cols(tile) != 0) tile = o.tile;   // override does not fit: planned tile
+        rc = launch_conv_op(c, o, N, c->conv_impl, tile, s, &e);
+        if (rc != NBC_OK) return rc;
         break;
       }
       case OP_MAXPOOL:
@@ -472,6 +477,50 @@ static int collect_profile(nbc_ctx* c) {
 }
 
 extern "C" {
+
+int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W, int reps, void* hip_stream) {
+  if (!c || !x_dev) return set_error(NBC_ERR_INVALID, "nbc_autotune: null argument");
+  if (reps < 1) reps = 3;
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  // one real forward first: every activation buffer then holds realistic data for the timed launches
+  int rc = nbc_forward(c, x_dev, x_dtype, N, H, W, nullptr, nullptr, nullptr, NBC_LABEL_U8, nullptr, 0, hip_stream);
+  if (rc != NBC_OK) return rc;
+  NBC_HIP(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  NBC_HIP(hipEventCreate(&e0));
+  NBC_HIP(hipEventCreate(&e1));
+  Plan& P = c->plan;
+  for (Op& o : P.ops) {
+    if (o.kind != OP_CONV) continue;
+    float best_ms = 1e30f;
+    int best = o.tile;
+    for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
+      if (o.Co % conv_tile_cols(tile) != 0) continue;
+      hipError_t e = hipSuccess;
+      rc = launch_conv_op(c, o, N, 1, tile, s, &e);                       // warm-up (and attribute set-up)
+      if (rc != NBC_OK || e != hipSuccess) continue;
+      (void)hipEventRecord(e0, s);
+      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, N, 1, tile, s, &e);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) continue;
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+      if (ms < best_ms) { best_ms = ms; best = tile; }
+    }
+    o.tile = best;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return NBC_OK;
+}
+
+int nbc_get_plan_tiles(nbc_ctx* c, int32_t* tiles, int capacity) {
+  if (!c || !tiles) return set_error(NBC_ERR_INVALID, "nbc_get_plan_tiles: null argument");
+  int n = 0;
+  for (const Op& o : c->plan.ops)
+    if (o.kind == OP_CONV) { if (n < capacity) tiles[n] = o.tile; ++n; }
+  return n;
+}
 
 int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, int H, int W,
                         float* logits_full_dev, void* labels_dev, int labels_dtype,

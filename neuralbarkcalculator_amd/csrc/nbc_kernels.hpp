@@ -32,7 +32,7 @@ struct ConvArgs {
 hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
 
 // v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co).
-enum { CONV_TILE_128x64 = 0, CONV_TILE_128x128 = 1, CONV_TILE_256x128 = 2, CONV_TILE_256x256 = 3, CONV_TILE_COUNT = 4 };
+constexpr int CONV_TILE_COUNT = 7;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 int choose_conv_tile(int M, int Co);

@@ -241,8 +241,25 @@ class FCNResNet50:
 
     def set_conv_impl(self, impl: int = 1, tile: int = -1):
         """Tuning/test knob: impl 1 = LDS-DMA ring kernel, 0 = register-staged kernel; tile -1 = auto,
-        0..3 = 128x64 / 128x128 / 256x128 / 256x256."""
+        0..6 = 128x64 / 128x128 / 256x128 / 256x256 / 128x128 (4 stages) / 128x256 / 256x64."""
         _lib.check(self._lib.nbc_set_conv_impl(self._require_ctx(), int(impl), int(tile)), "nbc_set_conv_impl")
+
+    def autotune(self, x: torch.Tensor, reps: int = 3):
+        """Measure every conv tile shape on every layer for x's (N,H,W) and keep the fastest per
+        layer (results are tile-independent).  Returns the chosen tile ids in launch order."""
+        n, h, w = self._check_input(x)
+        x = x.contiguous()
+        x_dtype = _lib.IN_F32_NCHW if x.dtype == torch.float32 else _lib.IN_U8_NHWC
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.nbc_autotune(self._ctx, x.data_ptr(), x_dtype, n, h, w, int(reps), stream),
+                       "nbc_autotune")
+        return self.plan_tiles()
+
+    def plan_tiles(self):
+        buf = (C.c_int32 * 64)()
+        n = self._lib.nbc_get_plan_tiles(self._require_ctx(), buf, 64)
+        return [int(buf[i]) for i in range(min(n, 64))]
 
     def set_keep_activations(self, on: bool):
         _lib.check(self._lib.nbc_set_keep_activations(self._require_ctx(), int(on)))
