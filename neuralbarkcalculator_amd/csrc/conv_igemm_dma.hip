@@ -117,9 +117,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       const int m = m0 + row;
       a_coff[i] = (ps ^ ((row >> 1) & 7)) * 16;     // logical chunk this slot holds
       if (m < p.M) {
-        const int img = m / hw;
+        // integer division by a run-time value costs ~30 VALU instructions each; the common
+        // shapes avoid both (one image: no image index; power-of-two width: a shift)
+        const int img = p.N == 1 ? 0 : m / hw;
         const int rem = m - img * hw;
-        const int oy = rem / p.Wo;
+        const int oy = p.wo_shift >= 0 ? (rem >> p.wo_shift) : rem / p.Wo;
         const int ox = rem - oy * p.Wo;
         a_iy0[i] = oy * p.stride - p.pad;
         a_ix0[i] = ox * p.stride - p.pad;
@@ -163,23 +165,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   };
   if constexpr (!STEM) set_tap(0, 0);
 
-  auto issue_step = [&](int t, int stage) {
-    const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
-    const unsigned sb = sa + A_BYTES;
-    if constexpr (!STEM) {
-#pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) {
+  // DMA d (0..L-1: activation passes first, then weight passes) of K-step t into ring slot `stage`.
+  auto issue_one = [&](int d, int t, unsigned sa) {
+    if (d < A_PASSES) {
+      const int i = d;
+      if constexpr (!STEM) {
         dma16(a_ptr[i], sa + (unsigned)(ROWS_PER_PASS * 128 * i));
         a_ptr[i] += a_inc[i];
-      }
-      if (++ld_cb == cblocks) {                    // wave-uniform: next K-step starts a new tap
-        ld_cb = 0;
-        if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
-        if (ld_kh < p.KH) set_tap(ld_kh, ld_kw);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_PASSES; ++i) {
+      } else {
         const int tap = t * 8 + (a_coff[i] >> 4);      // stem: one chunk = one tap's padded pixel
         const int kh = tap / p.KW, kw = tap - kh * p.KW;
         const int iy = a_iy0[i] + kh * p.dil, ix = a_ix0[i] + kw * p.dil;
@@ -188,12 +181,32 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
         const unsigned char* src = ok ? xb + off : zpage;
         dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
       }
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      dma16(wsrc[i], sb + (unsigned)(ROWS_PER_PASS * 128 * i));
+    } else {
+      const int i = d - A_PASSES;
+      dma16(wsrc[i], sa + (unsigned)(A_BYTES + ROWS_PER_PASS * 128 * i));
       wsrc[i] += 128;
     }
+  };
+  // The L DMAs of a K-step are issued in four parts so that the main loop can slot one part behind
+  // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
+  auto issue_part = [&](int part, int t, int stage) {
+    const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
+#pragma unroll
+    for (int d = 0; d < L; ++d)
+      if (d * 4 / L == part) issue_one(d, t, sa);
+    if constexpr (!STEM) {
+      if (part == 3) {
+        if (++ld_cb == cblocks) {                  // wave-uniform: next K-step starts a new tap
+          ld_cb = 0;
+          if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
+          if (ld_kh < p.KH) set_tap(ld_kh, ld_kw);
+        }
+      }
+    }
+  };
+  auto issue_step = [&](int t, int stage) {
+#pragma unroll
+    for (int part = 0; part < 4; ++part) issue_part(part, t, stage);
   };
 
   // ---- MFMA geometry
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 
   // Fragments are double-buffered in registers: the ds_read_b128 of chunk pair ks+1 are issued
   // before the MFMAs of chunk pair ks, so LDS latency hides under the matrix pipe.
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, bool do_issue, int t_issue, int issue_stage) {
     const unsigned char* sa = smem + stage * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
     uint4 pf[2][MT], wf[2][NT];
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
           }
         }
       if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
+      if (do_issue) issue_part(ks, t_issue, issue_stage);   // wave-uniform branch
     }
   };
 
@@ -274,8 +288,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
-    compute(t % S);
+    // the ring slot of step t-1 is free from here on: its refill (step t+S-1) is issued in four
+    // parts, one behind each MFMA cluster of this step
+    compute(t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
   }
   // last K-step, peeled: every DMA has retired, so the identity (residual) tile of the epilogue is
   // requested here and its HBM/MALL latency hides under the last MFMAs and the transposes below.
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
         }
     }
   }
-  compute((T - 1) % S);
+  compute((T - 1) % S, false, 0, 0);
 
   // ---- epilogue.
   // The accumulators hold, per lane, one pixel and groups of four channels: stored as they stand,

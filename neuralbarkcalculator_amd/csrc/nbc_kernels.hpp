@@ -25,6 +25,7 @@ struct ConvArgs {
   int ksteps;
   int relu;
   int stem;             // one 16-byte chunk per tap (Ci*elem == 16 bytes)
+  int wo_shift;         // log2(Wo) when Wo is a power of two, else -1
 };
 
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_32x32x16_bf16)
