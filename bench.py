@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0..3 force a tile shape (A/B runs)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default per-layer tile choice")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent batch-1 forwards kept in flight on separate HIP streams (each its own workspace)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch records (JSON) to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,7 +131,8 @@ def main():
     model.set_conv_impl(args.conv_impl, args.conv_tile)
     tiles = None
     if not args.no_autotune and args.conv_impl == 1 and args.conv_tile < 0:
-        tiles = model.autotune(batches[0])       # setup: per-layer tile shape by measurement
+        objective = "throughput" if max(1, args.streams) > 1 else "latency"
+        tiles = model.autotune(batches[0], objective=objective)   # setup: per-layer tile shape by measurement
     nstreams = max(1, args.streams)
     models = [model]
     for _ in range(nstreams - 1):
@@ -139,7 +140,7 @@ def main():
         m2.reserve(args.batch, H, W)
         m2.set_conv_impl(args.conv_impl, args.conv_tile)
         if tiles is not None:
-            m2.autotune(batches[0])
+            m2.autotune(batches[0], objective=objective)
         models.append(m2)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nstreams - 1)]
     torch.cuda.synchronize()
@@ -174,13 +175,20 @@ def main():
     torch.cuda.synchronize()
     # (1) the timed region of the contract: exactly K steps, nothing but the hot path in it
     dt = timed_region(args.steps)
-    # (2) the same K steps again with a HIP event between every launch (on the forward's stream):
-    # per-launch durations for the roofline.  Kept out of (1) because the event packets cost ~8 % of
-    # a batch-1 step; its wall time is reported as roofline.instrumented_ms_per_step.
-    records, dt_events = [], None
+    # (2) roofline region: the same K steps on ONE stream with a HIP event between every launch
+    # (on the forward's stream) and the tile choice tuned for a launch running alone -- the
+    # per-launch durations of the dominant kernel.  Kept out of (1) because event packets cost
+    # ~8 % of a batch-1 step and overlapped launches would inflate each other's durations; its
+    # wall time is reported as roofline.instrumented_ms_per_step.
+    records, dt_events, dt_single = [], None, None
     if not args.no_op_events:
+        if tiles is not None and nstreams > 1:
+            model.autotune(batches[0], objective="latency")
+        for i in range(min(args.warmup, 3)):
+            step(i, 0)
+        dt_single = timed_region(args.steps, 0)      # single stream, no events: reference
         model.set_profiling(True)
-        dt_events = timed_region(args.steps, 0)      # one stream: clean per-launch durations
+        dt_events = timed_region(args.steps, 0)
         records = model.op_records()
         model.set_profiling(False)
 
@@ -210,6 +218,10 @@ def main():
                    "autotuned_tiles": tiles},
         "setup_s": t_setup,
     }
+    if dt_single is not None:
+        out["single_stream"] = {"value": world * args.batch * args.steps / dt_single,
+                                "ms_per_step": 1e3 * dt_single / args.steps,
+                                "note": "same K steps on one stream, latency-tuned tiles, no per-launch events"}
 
     if records and args.dump_ops:
         with open(args.dump_ops, "w") as f:
@@ -223,7 +235,8 @@ def main():
         tot_ms = sum(r["ms"] for r in records)
         ach = flops / (ms * 1e-3) / 1e12
         out["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_kernel<%s,BN=128> (all non-stem convs with Cout%%128==0)" % args.precision,
+            "measured_on": "one stream, HIP event between launches, latency-tuned tiles (second region of K steps)",
+            "bound": "mfma", "kernel": "conv_dma_kernel<%s> (LDS-DMA implicit GEMM; all non-stem convs with Cout%%128==0)" % args.precision,
             "achieved": ach, "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
             "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None,
             "launches_per_step": len(dom), "flops_per_step": flops, "avg_launch_ms": ms / max(1, len(dom)),

@@ -160,7 +160,9 @@ int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
  * depend on the tile (same K order, one accumulator per output), only speed does.  The choice is
  * part of the plan and is dropped when the plan is rebuilt for another (N,H,W).
  * nbc_get_plan_tiles copies the tile id of each conv launch of the plan; returns their number. */
-int nbc_autotune(nbc_ctx* ctx, const void* x_dev, int x_dtype, int N, int H, int W, int reps, void* hip_stream);
+int nbc_autotune(nbc_ctx* ctx, const void* x_dev, int x_dtype, int N, int H, int W, int reps, int objective,
+                 void* hip_stream);   /* objective 0: time of the launch alone; 1: time x fraction of the 256
+                                         CUs it occupies (forwards overlapped on several streams) */
 int nbc_get_plan_tiles(nbc_ctx* ctx, int32_t* tiles, int capacity);
 
 /* ---- debugging / measurement ----------------------------------------------------------- */

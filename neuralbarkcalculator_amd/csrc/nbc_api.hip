@@ -481,7 +481,8 @@ static int collect_profile(nbc_ctx* c) {
 
 extern "C" {
 
-int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W, int reps, void* hip_stream) {
+int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W, int reps, int objective,
+                 void* hip_stream) {
   if (!c || !x_dev) return set_error(NBC_ERR_INVALID, "nbc_autotune: null argument");
   if (reps < 1) reps = 3;
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -508,6 +509,12 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
       if (hipEventSynchronize(e1) != hipSuccess) continue;
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+      if (objective == 1) {
+        // throughput objective: several forwards run concurrently on other streams, so a launch that
+        // fills only part of the chip costs only that part: weigh the time by the fraction of CUs used
+        const int tiles = ((N * o.Ho * o.Wo + conv_tile_rows(tile) - 1) / conv_tile_rows(tile)) * (o.Co / conv_tile_cols(tile));
+        if (tiles < 256) ms *= (float)tiles / 256.0f;
+      }
       if (ms < best_ms) { best_ms = ms; best = tile; }
     }
     o.tile = best;

@@ -244,15 +244,18 @@ class FCNResNet50:
         0..6 = 128x64 / 128x128 / 256x128 / 256x256 / 128x128 (4 stages) / 128x256 / 256x64."""
         _lib.check(self._lib.nbc_set_conv_impl(self._require_ctx(), int(impl), int(tile)), "nbc_set_conv_impl")
 
-    def autotune(self, x: torch.Tensor, reps: int = 3):
+    def autotune(self, x: torch.Tensor, reps: int = 3, objective: str = "latency"):
         """Measure every conv tile shape on every layer for x's (N,H,W) and keep the fastest per
-        layer (results are tile-independent).  Returns the chosen tile ids in launch order."""
+        layer (results are tile-independent).  objective "latency" minimises each launch alone;
+        "throughput" weighs a launch by the share of the chip it occupies (use it when several
+        forwards overlap on different streams).  Returns the chosen tile ids in launch order."""
         n, h, w = self._check_input(x)
         x = x.contiguous()
         x_dtype = _lib.IN_F32_NCHW if x.dtype == torch.float32 else _lib.IN_U8_NHWC
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(self._lib.nbc_autotune(self._ctx, x.data_ptr(), x_dtype, n, h, w, int(reps), stream),
+            _lib.check(self._lib.nbc_autotune(self._ctx, x.data_ptr(), x_dtype, n, h, w, int(reps),
+                                              1 if objective == "throughput" else 0, stream),
                        "nbc_autotune")
         return self.plan_tiles()
 

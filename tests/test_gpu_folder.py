@@ -1,0 +1,65 @@
+"""End-to-end folder prediction on the GPU (BASELINE.json configs[4]: weights loaded from a local
+.pt through load_state_dict, --exclude_nodes remap, label PNG + CSV match against the CPU oracle
+driven through the same post-processing)."""
+import csv
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from neuralbarkcalculator_amd import predict as drv
+from neuralbarkcalculator_amd import synth
+from neuralbarkcalculator_amd.postprocess import remove_small_zones
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("exclude_nodes", [False, True])
+def test_predict_folder_matches_oracle(tmp_path, oracle_model, sd_np, built_lib, exclude_nodes):
+    from oracle.fcn_resnet50_oracle import predict_labels
+    root = str(tmp_path)
+    layout = [("epinette_gelee", "a01.bmp", 30, 256, 256), ("epinette_gelee", "a02.png", 31, 200, 256),
+              ("sapin", "s1.png", 32, 256, 256), ("sapin", "s2.bmp", 33, 136, 256),
+              ("epinette_non_gelee", "n1.png", 34, 256, 256), ("sapin", "s0.png", 35, 256, 256),
+              ("epinette_gelee", "a03.png", 36, 256, 256), ("epinette_non_gelee", "n0.png", 37, 264, 256)]
+    frames = {}
+    for wood, name, idx, h, w in layout:
+        d = os.path.join(root, "samples", wood)
+        os.makedirs(d, exist_ok=True)
+        img = synth.make_frame(idx, h, w)
+        Image.fromarray(img, mode="RGB").save(os.path.join(d, name))
+        frames[(wood, name.replace("bmp", "png"))] = img
+    ckpt = os.path.join(root, "best_model.pt")
+    torch.save({k: torch.from_numpy(v) for k, v in sd_np.items()}, ckpt)     # predict.py:57 loads a local file
+
+    drv.predict_folder(root, ckpt, precision="fp32", exclude_nodes=exclude_nodes, device_index=0)
+
+    rows = list(csv.reader(open(os.path.join(root, "results", "final_stats.csv")), delimiter="\t"))
+    assert rows[0] == drv.CSV_HEADER and len(rows) == 1 + len(layout)
+    order = [(n, w) for _, n, w in drv.list_images(os.path.join(root, "processed"))]
+    assert [(r[0], r[1]) for r in rows[1:]] == order
+    assert order[0][1] == "epinette_gelee" and order[-1][1] == "sapin"        # dataset.py:50 order
+    total_flips = 0
+    for row in rows[1:]:
+        name, wood = row[0], row[1]
+        img = frames[(wood, name)]
+        if img.shape[0] == img.shape[1]:
+            pass                                                               # non-black frames: trim_black keeps all rows
+        x = torch.from_numpy(synth.normalize_frame(img))[None]
+        lab = predict_labels(oracle_model, x)[0][0].numpy().astype(np.uint8)
+        lab = remove_small_zones(lab)                                          # models.py:271
+        if exclude_nodes:
+            lab[lab == 2] = 1                                                  # models.py:273-276
+        got = np.asarray(Image.open(os.path.join(root, "results", "outputs", wood, name)))
+        assert got.dtype == np.uint8 and set(np.unique(got)) <= {0, 127, 255}
+        flips = int((got != drv.label_png(lab)).sum())
+        total_flips += flips
+        if flips == 0:
+            assert row == drv.stats_row(name, wood, lab.shape[0], lab.shape[1], int((lab == 1).sum()), int((lab == 2).sum()))
+        if exclude_nodes:
+            assert 255 not in np.unique(got) and row[4] == "0.00000"
+    # fp32 parity mode: label PNGs are bit-identical except where a logit tie flips a pixel (rare;
+    # remove_small_zones can enlarge such a flip to a zone of < 150 px)
+    assert total_flips <= 150, total_flips
