@@ -246,6 +246,18 @@ def main():
             "sum_kernel_ms_per_step": tot_ms,
             "instrumented_ms_per_step": 1e3 * dt_events / args.steps,
         }
+        # HBM/fabric traffic of the dominant kernel comes from rocprofv3 PMC passes (they cannot run
+        # inside this process); scripts/profile_pmc.sh + scripts/pmc_summary.py commit a summary
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.precision)
+        if os.path.exists(pmc):
+            try:
+                t = json.load(open(pmc))["dominant_kernel"]
+                out["roofline"]["traffic"] = t["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = ("bytes per launch of the dominant kernel, rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE "
+                                                   "from profiles/%s (L2-miss traffic incl. Infinity-Cache hits); algorithmic %.0f"
+                                                   % (os.path.basename(pmc), t["algorithmic_bytes_per_launch"]))
+            except (OSError, KeyError, ValueError):
+                pass
         worst = sorted(records, key=lambda r: -r["ms"])[:6]
         out["top_ops"] = [{"name": r["name"], "ms": round(r["ms"], 4),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 else 0} for r in worst]
