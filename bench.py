@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
     ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0..3 force a tile shape (A/B runs)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (one-GPU box), implies a gloo process group")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default per-layer tile choice")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batch-1 forwards kept in flight on separate HIP streams (each its own workspace)")
@@ -104,8 +107,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.share_gpu:
+            local_rank = 0
+            args.dist_backend = "gloo"
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
