@@ -277,9 +277,109 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   const int n_slab = n0 + wn * SLAB_CH;
   uint4 rpre[RES_PREFETCH ? MT : 1][RES_PREFETCH ? PASSES : 1];
 
+  const int T = p.ksteps;
+  auto prefetch_identity = [&]() {
+    if constexpr (RES_PREFETCH) {
+      if (resb) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int ps2 = 0; ps2 < PASSES; ++ps2) {
+            int m = m0 + (wm * MT + i) * 32 + ps2 * PIX_PER_PASS + o_pix;
+            m = m < p.M ? m : p.M - 1;                 // tail rows read a valid row; never stored
+            rpre[i][ps2] = *reinterpret_cast<const uint4*>(
+                resb + ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB);
+          }
+      }
+    }
+  };
+
+  if constexpr (VAR == 2) {
+    // ---- ping-pong pipeline (8 waves = 2 per SIMD).  The two waves of a SIMD (w and w+4) alternate
+    // roles every barrier: one runs an MFMA cluster from fragments already in registers while the
+    // other reads its next fragments from LDS and issues its share of the DMAs, so the matrix pipe
+    // always has a wave to issue from (the one-barrier loop above leaves both waves of a SIMD
+    // waiting on LDS / the barrier at the same time: 45 % idle matrix pipe measured).
+    // Phases are separated by s_barrier; waves 4-7 run one phase behind waves 0-3.
+    //   LOAD(t,c):    ds_read the fragments of cluster c of K-step t; issue 1/CL of the DMAs of step
+    //                 t+S-1; after the last cluster wait (counted vmcnt) for this wave's DMAs of
+    //                 step t+1; wait lgkmcnt(0) so that every LDS read of the slot has completed
+    //                 before the barrier that lets the other group refill it; barrier.
+    //   COMPUTE(t,c): the MFMAs of the cluster; barrier.
+    // RAW: step t+1 is read first in phase 4(t+1) (group 0); both groups waited for their DMAs of
+    // step t+1 before barriers 4t+2 / 4t+3.  WAR: the slot of step t-1 is refilled from phase 4t on;
+    // its last reads (group 1, LOAD(t-1,last)) completed before barrier 4t-1.
+    static_assert(WM * WN == 8, "ping-pong needs two waves per SIMD");
+    constexpr int CL = ((MT + NT) * 16 <= 64) ? 1 : 2;     // keep a cluster's fragments <= 64 VGPRs
+    constexpr int KS_PER = 4 / CL;
+    const int grp = wave >> 2;
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+      if (s < T) issue_step(s, s);
+    if (T >= S - 1) wait_vmcnt<(S - 2) * L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+      const unsigned char* sa = smem + (t % S) * STAGE_BYTES;
+      const unsigned char* sb = sa + A_BYTES;
+      const bool refill = t + S - 1 < T;
+#pragma unroll
+      for (int c = 0; c < CL; ++c) {
+        uint4 pf[KS_PER][MT], wf[KS_PER][NT];
+#pragma unroll
+        for (int q = 0; q < KS_PER; ++q) {
+          const int chunk = 2 * (c * KS_PER + q) + h;
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            pf[q][i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * MT + i) * 32 + r, chunk));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            wf[q][j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
+        }
+        if (refill) {
+#pragma unroll
+          for (int part = c * KS_PER; part < (c + 1) * KS_PER; ++part) issue_part(part, t + S - 1, (t + S - 1) % S);
+        }
+        if (c == CL - 1) {
+          if (t + S <= T) wait_vmcnt<(S - 2) * L>();
+          else wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < KS_PER; ++q)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              if constexpr (PREC == 1) {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, wf[q][j]), __builtin_bit_cast(bf16x8, pf[q][i]), acc[j][i], 0, 0, 0);
+              } else {
+                const float4 wv = __builtin_bit_cast(float4, wf[q][j]);
+                const float4 pv = __builtin_bit_cast(float4, pf[q][i]);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, pv.x, acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, pv.y, acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, pv.z, acc[j][i], 0, 0, 0);
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, acc[j][i], 0, 0, 0);
+              }
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();    // every wave executes the same number of barriers
+    prefetch_identity();
+  } else {
   // ---- pipeline.  Steps beyond T issue nothing; the counted wait then over-waits, which is safe
   // (vmcnt retires in order), and the tail uses vmcnt(0).
-  const int T = p.ksteps;
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < T) issue_step(s, s);
@@ -296,20 +396,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // requested here and its HBM/MALL latency hides under the last MFMAs and the transposes below.
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
-  if constexpr (RES_PREFETCH) {
-    if (resb) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int ps2 = 0; ps2 < PASSES; ++ps2) {
-          int m = m0 + (wm * MT + i) * 32 + ps2 * PIX_PER_PASS + o_pix;
-          m = m < p.M ? m : p.M - 1;                 // tail rows read a valid row; never stored
-          rpre[i][ps2] = *reinterpret_cast<const uint4*>(
-              resb + ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB);
-        }
-    }
-  }
+  prefetch_identity();
   compute((T - 1) % S, false, 0, 0);
+  }
 
   // ---- epilogue.
   // The accumulators hold, per lane, one pixel and groups of four channels: stored as they stand,
@@ -386,12 +475,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   }
 }
 
-template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM>
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 0>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int smem = S * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, 0>;
+  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -413,6 +502,7 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch)
 //   5   128x256   2x4            64x64      3       144 KiB  1
 //   6   256x64    4x2            64x32      3       120 KiB  1
+//   7..10 = tiles 2, 3, 5, 6 with the ping-pong pipeline
 template <int PREC, bool STEM>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
@@ -423,12 +513,17 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM>(a, s);
     case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM>(a, s);
     case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM>(a, s);
+    // ping-pong pipeline (two waves per SIMD alternate LDS/DMA and MFMA phases), non-stem only
+    case 7: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
+    case 8: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, 2>(a, s); else return hipErrorInvalidValue;
+    case 9: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
+    case 10: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 256, 256, 128, 256};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 128, 256, 256, 64};
 
 }  // namespace
 

@@ -500,6 +500,7 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
     int best = o.tile;
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
       if (o.Co % conv_tile_cols(tile) != 0) continue;
+      if (tile >= 7 && c->layout.convs[o.unit].stem) continue;   // ping-pong variants: non-stem only
       hipError_t e = hipSuccess;
       rc = launch_conv_op(c, o, N, 1, tile, s, &e);                       // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
