@@ -190,6 +190,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // The L DMAs of a K-step are issued in four parts so that the main loop can slot one part behind
   // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
   auto issue_part = [&](int part, int t, int stage) {
+    if constexpr (VAR == 4) return;                  // timing-only ablation: no refill DMAs in the loop
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
 #pragma unroll
     for (int d = 0; d < L; ++d)
@@ -240,6 +241,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     for (int ks = 0; ks < 4; ++ks) {
       if (ks + 1 < 4) load_frags(ks + 1, pf[(ks + 1) & 1], wf[(ks + 1) & 1]);
       if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
+      if constexpr (VAR == 3) {                        // timing-only ablation: fragments read, no MFMA
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(pf[ks & 1][i]));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[ks & 1][j]));
+      } else
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -556,6 +563,13 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   }
   if (tile < 0) tile = choose_conv_tile(a.M, a.Co);
   if (tile < 0 || tile >= CONV_TILE_COUNT || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
+  // NBC_CONV_ABLATE=1 (no MFMA) / 2 (no refill DMA): timing-only builds of the bf16 256x256 and
+  // 128x256 tiles, results are garbage.  Never set outside an experiment.
+  static const int ablate = [] { const char* e = getenv("NBC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+  if (ablate && precision == 1 && !a.stem && (tile == 3 || tile == 5)) {
+    if (ablate == 1) return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 3>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 3>(a, s);
+    return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 4>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 4>(a, s);
+  }
   if (precision == 0) return a.stem ? launch_tile<0, true>(a, tile, s) : launch_tile<0, false>(a, tile, s);
   return a.stem ? launch_tile<1, true>(a, tile, s) : launch_tile<1, false>(a, tile, s);
 }

@@ -414,7 +414,8 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         break;
       case OP_CONV: {
         int tile = c->conv_tile;
-        if (tile < 0 || o.Co % conv_tile_cols(tile) != 0) tile = o.tile;   // override does not fit: planned tile
+        if (tile < 0 || o.Co % conv_tile_cols(tile) != 0 || (tile >= 7 && c->layout.convs[o.unit].stem))
+          tile = o.tile;                                  // override does not fit this layer: planned tile
         rc = launch_conv_op(c, o, N, c->conv_impl, tile, s, &e);
         if (rc != NBC_OK) return rc;
         break;
