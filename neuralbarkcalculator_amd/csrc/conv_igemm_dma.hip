@@ -243,9 +243,11 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
       if constexpr (VAR == 3) {                        // timing-only ablation: fragments read, no MFMA
 #pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(pf[ks & 1][i]));
+        for (int i = 0; i < MT; ++i)
+          asm volatile("" ::"v"(pf[ks & 1][i].x), "v"(pf[ks & 1][i].y), "v"(pf[ks & 1][i].z), "v"(pf[ks & 1][i].w));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(wf[ks & 1][j]));
+        for (int j = 0; j < NT; ++j)
+          asm volatile("" ::"v"(wf[ks & 1][j].x), "v"(wf[ks & 1][j].y), "v"(wf[ks & 1][j].z), "v"(wf[ks & 1][j].w));
       } else
 #pragma unroll
       for (int j = 0; j < NT; ++j)
