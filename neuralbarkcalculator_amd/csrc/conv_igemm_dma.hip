@@ -57,6 +57,20 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       : "memory");
 }
 
+// 4-byte-per-lane LDS-DMA (64 lanes -> 256 bytes at lds_base): used only to pull lines into L2.
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -76,7 +90,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   constexpr int ROWS_PER_PASS = THREADS / 8;
   constexpr int A_PASSES = BM / ROWS_PER_PASS;
   constexpr int B_PASSES = BN / ROWS_PER_PASS;
-  constexpr int L = A_PASSES + B_PASSES;          // DMA instructions per thread per K-step
+  constexpr bool PF = (VAR == 6);                  // software L2 prefetcher (see below)
+  constexpr int PF_DIST = 6;                       // K-steps the prefetcher runs ahead of the DMAs
+  constexpr int L = A_PASSES + B_PASSES + (PF ? 1 : 0);   // vector-memory ops per thread per K-step
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must fill whole passes");
   static_assert(S >= 2 && S <= 4, "2..4 LDS stages");
 
@@ -165,6 +181,64 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   };
   if constexpr (!STEM) set_tap(0, 0);
 
+  // ---- software L2 prefetcher (VAR 6).  A ring slot needs ALL its lines before the barrier, so
+  // one L2 miss (first touch of a weight / activation line by this XCD: Infinity-Cache or HBM
+  // latency) stalls the whole K-step, and the 96 KiB of DMAs a CU can keep in flight do not cover
+  // that latency at the rate the MFMAs consume data.  Thread i of the block therefore touches, with
+  // a 4-byte LDS-DMA into a scratch line, the 128-byte line that row i of the tile (pixel rows
+  // first, then weight rows) will need PF_DIST K-steps later: by the time the real DMA is issued the
+  // line is an L2 hit.  One extra vector-memory op per K-step, counted in L.
+  const unsigned char* pf_ptr = zpage;
+  int pf_inc = 0, pf_kh = 0, pf_kw = 0, pf_cb = 0, pf_t = 0;
+  int pf_iy0 = -(1 << 24), pf_ix0 = 0, pf_img = 0;
+  const bool pf_is_a = tid < BM;
+  const bool pf_is_w = !pf_is_a && tid < BM + BN;
+  auto pf_set_tap = [&]() {
+    if (pf_is_a) {
+      const int iy = pf_iy0 + pf_kh * p.dil, ix = pf_ix0 + pf_kw * p.dil;
+      const bool ok = pf_t < p.ksteps && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const long long off = (long long)(pf_img + iy * p.Wi + ix) * pix_bytes + pf_cb * 128;
+      pf_ptr = ok ? xb + off : zpage;
+      pf_inc = ok ? 128 : 0;
+    }
+  };
+  if constexpr (PF) {
+    pf_t = PF_DIST;
+    pf_cb = PF_DIST % cblocks;
+    const int tap = PF_DIST / cblocks;
+    pf_kh = tap / p.KW;
+    pf_kw = tap - pf_kh * p.KW;
+    if (pf_is_a) {
+      const int m = m0 + tid;
+      if (m < p.M) {
+        const int hw = p.Ho * p.Wo;
+        const int img = p.N == 1 ? 0 : m / hw;
+        const int rem = m - img * hw;
+        const int oy = p.wo_shift >= 0 ? (rem >> p.wo_shift) : rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        pf_iy0 = oy * p.stride - p.pad;
+        pf_ix0 = ox * p.stride - p.pad;
+        pf_img = img * p.Hi * p.Wi;
+      }
+      pf_set_tap();
+    } else if (pf_is_w) {
+      pf_ptr = wb + (size_t)(n0 + tid - BM) * wrow_bytes + (size_t)PF_DIST * 128;
+      pf_inc = 128;
+      if (PF_DIST >= p.ksteps) { pf_ptr = zpage; pf_inc = 0; }
+    }
+  }
+  auto pf_issue = [&]() {
+    dma4(pf_ptr, smem_base + (unsigned)(S * STAGE_BYTES) + (unsigned)wave * 256u);
+    pf_ptr += pf_inc;
+    ++pf_t;
+    if (++pf_cb == cblocks) {                      // wave-uniform
+      pf_cb = 0;
+      if (++pf_kw == p.KW) { pf_kw = 0; ++pf_kh; }
+      pf_set_tap();
+    }
+    if (pf_is_w && pf_t >= p.ksteps) { pf_ptr = zpage; pf_inc = 0; }
+  };
+
   // DMA d (0..L-1: activation passes first, then weight passes) of K-step t into ring slot `stage`.
   auto issue_one = [&](int d, int t, unsigned sa) {
     if (d < A_PASSES) {
@@ -191,10 +265,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
   auto issue_part = [&](int part, int t, int stage) {
     if constexpr (VAR == 4) return;                  // timing-only ablation: no refill DMAs in the loop
+    if constexpr (PF) { if (part == 0) pf_issue(); }
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
+    constexpr int ND = A_PASSES + B_PASSES;
 #pragma unroll
-    for (int d = 0; d < L; ++d)
-      if (d * 4 / L == part) issue_one(d, t, sa);
+    for (int d = 0; d < ND; ++d)
+      if (d * 4 / ND == part) issue_one(d, t, sa);
     if constexpr (!STEM) {
       if (part == 3) {
         if (++ld_cb == cblocks) {                  // wave-uniform: next K-step starts a new tap
@@ -487,7 +563,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 0>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr int smem = S * (BM + BN) * 128;
+  constexpr int smem = S * (BM + BN) * 128 + (VAR == 6 ? WM * WN * 256 : 0);
   static bool attr_set = false;
   auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
   if (!attr_set) {
@@ -511,7 +587,7 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch)
 //   5   128x256   2x4            64x64      3       144 KiB  1
 //   6   256x64    4x2            64x32      3       120 KiB  1
-//   7..10 = tiles 2, 3, 5, 6 with the ping-pong pipeline
+//   7..10 = tiles 2, 3, 5, 6 with the ping-pong pipeline; 11..13 = tiles 2, 3, 5 + L2 prefetcher
 template <int PREC, bool STEM>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
@@ -527,12 +603,16 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 8: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, 2>(a, s); else return hipErrorInvalidValue;
     case 9: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
     case 10: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
+    // software L2 prefetcher on top of tiles 2, 3, 5
+    case 11: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 6>(a, s); else return hipErrorInvalidValue;
+    case 12: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, 6>(a, s); else return hipErrorInvalidValue;
+    case 13: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 6>(a, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 256, 256, 128, 256};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 128, 256, 256, 64};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 256, 256, 128, 256, 256, 256, 128};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 128, 256, 256, 64, 128, 256, 256};
 
 }  // namespace
 
