@@ -265,12 +265,14 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
   auto issue_part = [&](int part, int t, int stage) {
     if constexpr (VAR == 4) return;                  // timing-only ablation: no refill DMAs in the loop
-    if constexpr (PF) { if (part == 0) pf_issue(); }
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
     constexpr int ND = A_PASSES + B_PASSES;
 #pragma unroll
     for (int d = 0; d < ND; ++d)
       if (d * 4 / ND == part) issue_one(d, t, sa);
+    // the prefetch op goes LAST in its group: vmcnt retires in order, and a guaranteed L2 miss in
+    // front of the group's DMAs would put the miss latency on every K-step's critical path
+    if constexpr (PF) { if (part == 3) pf_issue(); }
     if constexpr (!STEM) {
       if (part == 3) {
         if (++ld_cb == cblocks) {                  // wave-uniform: next K-step starts a new tap
@@ -470,7 +472,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     if (s < T) issue_step(s, s);
   for (int t = 0; t < T - 1; ++t) {
     // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
-    if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
+    // (with the prefetcher the op right behind step t's DMAs is step t's own prefetch: one more may stay)
+    if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L + (PF ? 1 : 0)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     // the ring slot of step t-1 is free from here on: its refill (step t+S-1) is issued in four
