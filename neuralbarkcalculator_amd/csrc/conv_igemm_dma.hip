@@ -476,9 +476,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L + (PF ? 1 : 0)>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    // the ring slot of step t-1 is free from here on: its refill (step t+S-1) is issued in four
-    // parts, one behind each MFMA cluster of this step
-    compute(t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
+    // the ring slot of step t-1 is free from here on.  With three or more stages its refill (step
+    // t+S-1) is issued in four parts, one behind each MFMA cluster of this step; with two stages the
+    // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
+    if constexpr (S == 2) {
+      if (t + 1 < T) issue_step(t + 1, (t + 1) % S);
+      compute(t % S, false, 0, 0);
+    } else {
+      compute(t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
+    }
   }
   // last K-step, peeled: every DMA has retired, so the identity (residual) tile of the epilogue is
   // requested here and its HBM/MALL latency hides under the last MFMAs and the transposes below.
