@@ -479,8 +479,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     // the ring slot of step t-1 is free from here on.  With three or more stages its refill (step
     // t+S-1) is issued in four parts, one behind each MFMA cluster of this step; with two stages the
     // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
-    if constexpr (S == 2) {
-      if (t + 1 < T) issue_step(t + 1, (t + 1) % S);
+    if constexpr (S == 2 || VAR == 7) {
+      if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
       compute(t % S, false, 0, 0);
     } else {
       compute(t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
@@ -616,12 +616,17 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 11: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 6>(a, s); else return hipErrorInvalidValue;
     case 12: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, 6>(a, s); else return hipErrorInvalidValue;
     case 13: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 6>(a, s); else return hipErrorInvalidValue;
+    // A/B: three-stage tiles 5, 2, 6, 0 with the refill issued at the top of the step
+    case 14: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
+    case 15: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
+    case 16: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
+    case 17: if constexpr (!STEM) return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 256, 256, 128, 256, 256, 256, 128};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 128, 256, 256, 64, 128, 256, 256};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 256, 256, 128, 256, 256, 256, 128, 128, 256, 256, 128};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 128, 256, 256, 64, 128, 256, 256, 256, 128, 64, 64};
 
 }  // namespace
 
