@@ -150,7 +150,7 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
 
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
  * register-staged reference kernel; tile = -1 (per-layer choice) or 0..6 = 128x64, 128x128,
- * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 7..10 = tiles 2,3,5,6 with the ping-pong pipeline (pixels x channels) forced wherever the
+ * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64 (pixels x channels) forced wherever the
  * layer's Cout allows it. */
 int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
 

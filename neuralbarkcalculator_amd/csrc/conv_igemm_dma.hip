@@ -57,20 +57,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       : "memory");
 }
 
-// 4-byte-per-lane LDS-DMA (64 lanes -> 256 bytes at lds_base): used only to pull lines into L2.
-__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dword %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_base)
-      : "memory");
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -90,9 +76,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   constexpr int ROWS_PER_PASS = THREADS / 8;
   constexpr int A_PASSES = BM / ROWS_PER_PASS;
   constexpr int B_PASSES = BN / ROWS_PER_PASS;
-  constexpr bool PF = (VAR == 6);                  // software L2 prefetcher (see below)
-  constexpr int PF_DIST = 6;                       // K-steps the prefetcher runs ahead of the DMAs
-  constexpr int L = A_PASSES + B_PASSES + (PF ? 1 : 0);   // vector-memory ops per thread per K-step
+  constexpr int L = A_PASSES + B_PASSES;          // DMA instructions per thread per K-step
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must fill whole passes");
   static_assert(S >= 2 && S <= 4, "2..4 LDS stages");
 
@@ -181,64 +165,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   };
   if constexpr (!STEM) set_tap(0, 0);
 
-  // ---- software L2 prefetcher (VAR 6).  A ring slot needs ALL its lines before the barrier, so
-  // one L2 miss (first touch of a weight / activation line by this XCD: Infinity-Cache or HBM
-  // latency) stalls the whole K-step, and the 96 KiB of DMAs a CU can keep in flight do not cover
-  // that latency at the rate the MFMAs consume data.  Thread i of the block therefore touches, with
-  // a 4-byte LDS-DMA into a scratch line, the 128-byte line that row i of the tile (pixel rows
-  // first, then weight rows) will need PF_DIST K-steps later: by the time the real DMA is issued the
-  // line is an L2 hit.  One extra vector-memory op per K-step, counted in L.
-  const unsigned char* pf_ptr = zpage;
-  int pf_inc = 0, pf_kh = 0, pf_kw = 0, pf_cb = 0, pf_t = 0;
-  int pf_iy0 = -(1 << 24), pf_ix0 = 0, pf_img = 0;
-  const bool pf_is_a = tid < BM;
-  const bool pf_is_w = !pf_is_a && tid < BM + BN;
-  auto pf_set_tap = [&]() {
-    if (pf_is_a) {
-      const int iy = pf_iy0 + pf_kh * p.dil, ix = pf_ix0 + pf_kw * p.dil;
-      const bool ok = pf_t < p.ksteps && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const long long off = (long long)(pf_img + iy * p.Wi + ix) * pix_bytes + pf_cb * 128;
-      pf_ptr = ok ? xb + off : zpage;
-      pf_inc = ok ? 128 : 0;
-    }
-  };
-  if constexpr (PF) {
-    pf_t = PF_DIST;
-    pf_cb = PF_DIST % cblocks;
-    const int tap = PF_DIST / cblocks;
-    pf_kh = tap / p.KW;
-    pf_kw = tap - pf_kh * p.KW;
-    if (pf_is_a) {
-      const int m = m0 + tid;
-      if (m < p.M) {
-        const int hw = p.Ho * p.Wo;
-        const int img = p.N == 1 ? 0 : m / hw;
-        const int rem = m - img * hw;
-        const int oy = p.wo_shift >= 0 ? (rem >> p.wo_shift) : rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        pf_iy0 = oy * p.stride - p.pad;
-        pf_ix0 = ox * p.stride - p.pad;
-        pf_img = img * p.Hi * p.Wi;
-      }
-      pf_set_tap();
-    } else if (pf_is_w) {
-      pf_ptr = wb + (size_t)(n0 + tid - BM) * wrow_bytes + (size_t)PF_DIST * 128;
-      pf_inc = 128;
-      if (PF_DIST >= p.ksteps) { pf_ptr = zpage; pf_inc = 0; }
-    }
-  }
-  auto pf_issue = [&]() {
-    dma4(pf_ptr, smem_base + (unsigned)(S * STAGE_BYTES) + (unsigned)wave * 256u);
-    pf_ptr += pf_inc;
-    ++pf_t;
-    if (++pf_cb == cblocks) {                      // wave-uniform
-      pf_cb = 0;
-      if (++pf_kw == p.KW) { pf_kw = 0; ++pf_kh; }
-      pf_set_tap();
-    }
-    if (pf_is_w && pf_t >= p.ksteps) { pf_ptr = zpage; pf_inc = 0; }
-  };
-
   // DMA d (0..L-1: activation passes first, then weight passes) of K-step t into ring slot `stage`.
   auto issue_one = [&](int d, int t, unsigned sa) {
     if (d < A_PASSES) {
@@ -266,13 +192,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   auto issue_part = [&](int part, int t, int stage) {
     if constexpr (VAR == 4) return;                  // timing-only ablation: no refill DMAs in the loop
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
-    constexpr int ND = A_PASSES + B_PASSES;
 #pragma unroll
-    for (int d = 0; d < ND; ++d)
-      if (d * 4 / ND == part) issue_one(d, t, sa);
-    // the prefetch op goes LAST in its group: vmcnt retires in order, and a guaranteed L2 miss in
-    // front of the group's DMAs would put the miss latency on every K-step's critical path
-    if constexpr (PF) { if (part == 3) pf_issue(); }
+    for (int d = 0; d < L; ++d)
+      if (d * 4 / L == part) issue_one(d, t, sa);
     if constexpr (!STEM) {
       if (part == 3) {
         if (++ld_cb == cblocks) {                  // wave-uniform: next K-step starts a new tap
@@ -318,7 +240,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks + 1 < 4) load_frags(ks + 1, pf[(ks + 1) & 1], wf[(ks + 1) & 1]);
-      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
       if constexpr (VAR == 3) {                        // timing-only ablation: fragments read, no MFMA
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -344,7 +265,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
             acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, acc[j][i], 0, 0, 0);
           }
         }
-      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
       if (do_issue) issue_part(ks, t_issue, issue_stage);   // wave-uniform branch
     }
   };
@@ -381,105 +301,27 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     }
   };
 
-  if constexpr (VAR == 2) {
-    // ---- ping-pong pipeline (8 waves = 2 per SIMD).  The two waves of a SIMD (w and w+4) alternate
-    // roles every barrier: one runs an MFMA cluster from fragments already in registers while the
-    // other reads its next fragments from LDS and issues its share of the DMAs, so the matrix pipe
-    // always has a wave to issue from (the one-barrier loop above leaves both waves of a SIMD
-    // waiting on LDS / the barrier at the same time: 45 % idle matrix pipe measured).
-    // Phases are separated by s_barrier; waves 4-7 run one phase behind waves 0-3.
-    //   LOAD(t,c):    ds_read the fragments of cluster c of K-step t; issue 1/CL of the DMAs of step
-    //                 t+S-1; after the last cluster wait (counted vmcnt) for this wave's DMAs of
-    //                 step t+1; wait lgkmcnt(0) so that every LDS read of the slot has completed
-    //                 before the barrier that lets the other group refill it; barrier.
-    //   COMPUTE(t,c): the MFMAs of the cluster; barrier.
-    // RAW: step t+1 is read first in phase 4(t+1) (group 0); both groups waited for their DMAs of
-    // step t+1 before barriers 4t+2 / 4t+3.  WAR: the slot of step t-1 is refilled from phase 4t on;
-    // its last reads (group 1, LOAD(t-1,last)) completed before barrier 4t-1.
-    static_assert(WM * WN == 8, "ping-pong needs two waves per SIMD");
-    constexpr int CL = ((MT + NT) * 16 <= 64) ? 1 : 2;     // keep a cluster's fragments <= 64 VGPRs
-    constexpr int KS_PER = 4 / CL;
-    const int grp = wave >> 2;
-#pragma unroll
-    for (int s = 0; s < S - 1; ++s)
-      if (s < T) issue_step(s, s);
-    if (T >= S - 1) wait_vmcnt<(S - 2) * L>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < T; ++t) {
-      const unsigned char* sa = smem + (t % S) * STAGE_BYTES;
-      const unsigned char* sb = sa + A_BYTES;
-      const bool refill = t + S - 1 < T;
-#pragma unroll
-      for (int c = 0; c < CL; ++c) {
-        uint4 pf[KS_PER][MT], wf[KS_PER][NT];
-#pragma unroll
-        for (int q = 0; q < KS_PER; ++q) {
-          const int chunk = 2 * (c * KS_PER + q) + h;
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-            pf[q][i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * MT + i) * 32 + r, chunk));
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            wf[q][j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
-        }
-        if (refill) {
-#pragma unroll
-          for (int part = c * KS_PER; part < (c + 1) * KS_PER; ++part) issue_part(part, t + S - 1, (t + S - 1) % S);
-        }
-        if (c == CL - 1) {
-          if (t + S <= T) wait_vmcnt<(S - 2) * L>();
-          else wait_vmcnt<0>();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int q = 0; q < KS_PER; ++q)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-              if constexpr (PREC == 1) {
-                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8, wf[q][j]), __builtin_bit_cast(bf16x8, pf[q][i]), acc[j][i], 0, 0, 0);
-              } else {
-                const float4 wv = __builtin_bit_cast(float4, wf[q][j]);
-                const float4 pv = __builtin_bit_cast(float4, pf[q][i]);
-                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, pv.x, acc[j][i], 0, 0, 0);
-                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, pv.y, acc[j][i], 0, 0, 0);
-                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, pv.z, acc[j][i], 0, 0, 0);
-                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, acc[j][i], 0, 0, 0);
-              }
-            }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();    // every wave executes the same number of barriers
-    prefetch_identity();
-  } else {
   // ---- pipeline.  Steps beyond T issue nothing; the counted wait then over-waits, which is safe
   // (vmcnt retires in order), and the tail uses vmcnt(0).
+  // First of all the block's BN scale/shift pairs go to a 2 KiB LDS table behind the ring (two
+  // LDS-DMAs of wave 0, older than every ring DMA, so the first counted wait covers them): the
+  // epilogue then reads them from LDS instead of paying an L2 round trip per 32-pixel slab.
+  if (wave == 0 && lane < BN / 4) {
+    dma16(p.scale + n0 + lane * 4, smem_base + (unsigned)(S * STAGE_BYTES));
+    dma16(p.shift + n0 + lane * 4, smem_base + (unsigned)(S * STAGE_BYTES) + 1024u);
+  }
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < T) issue_step(s, s);
   for (int t = 0; t < T - 1; ++t) {
     // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
-    // (with the prefetcher the op right behind step t's DMAs is step t's own prefetch: one more may stay)
-    if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L + (PF ? 1 : 0)>();
+    if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     // the ring slot of step t-1 is free from here on.  With three or more stages its refill (step
     // t+S-1) is issued in four parts, one behind each MFMA cluster of this step; with two stages the
     // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
-    if constexpr (S == 2 || VAR == 7) {
+    if constexpr (S == 2) {
       if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
       compute(t % S, false, 0, 0);
     } else {
@@ -492,7 +334,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   __builtin_amdgcn_s_barrier();
   prefetch_identity();
   compute((T - 1) % S, false, 0, 0);
-  }
 
   // ---- epilogue.
   // The accumulators hold, per lane, one pixel and groups of four channels: stored as they stand,
@@ -510,8 +351,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = j * 32 + 8 * g + 4 * h;      // channel inside the slab
-        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n_slab + nl);
-        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n_slab + nl);
+        const float4 sc = *reinterpret_cast<const float4*>(smem + S * STAGE_BYTES + (wn * SLAB_CH + nl) * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(smem + S * STAGE_BYTES + 1024 + (wn * SLAB_CH + nl) * 4);
         float4 v;
         v.x = __builtin_fmaf(acc[j][i][4 * g + 0], sc.x, sh.x);
         v.y = __builtin_fmaf(acc[j][i][4 * g + 1], sc.y, sh.y);
@@ -572,7 +413,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 0>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr int smem = S * (BM + BN) * 128 + (VAR == 6 ? WM * WN * 256 : 0);
+  constexpr int smem = S * (BM + BN) * 128 + 2048;     // ring + scale/shift table
   static bool attr_set = false;
   auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
   if (!attr_set) {
@@ -596,7 +437,6 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch)
 //   5   128x256   2x4            64x64      3       144 KiB  1
 //   6   256x64    4x2            64x32      3       120 KiB  1
-//   7..10 = tiles 2, 3, 5, 6 with the ping-pong pipeline; 11..13 = tiles 2, 3, 5 + L2 prefetcher
 template <int PREC, bool STEM>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
@@ -607,26 +447,12 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM>(a, s);
     case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM>(a, s);
     case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM>(a, s);
-    // ping-pong pipeline (two waves per SIMD alternate LDS/DMA and MFMA phases), non-stem only
-    case 7: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
-    case 8: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, 2>(a, s); else return hipErrorInvalidValue;
-    case 9: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
-    case 10: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, 2>(a, s); else return hipErrorInvalidValue;
-    // software L2 prefetcher on top of tiles 2, 3, 5
-    case 11: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 6>(a, s); else return hipErrorInvalidValue;
-    case 12: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, 6>(a, s); else return hipErrorInvalidValue;
-    case 13: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 6>(a, s); else return hipErrorInvalidValue;
-    // A/B: three-stage tiles 5, 2, 6, 0 with the refill issued at the top of the step
-    case 14: if constexpr (!STEM) return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
-    case 15: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
-    case 16: if constexpr (!STEM) return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
-    case 17: if constexpr (!STEM) return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, 7>(a, s); else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 256, 256, 128, 256, 256, 256, 128, 128, 256, 256, 128};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 128, 256, 256, 64, 128, 256, 256, 256, 128, 64, 64};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64};
 
 }  // namespace
 

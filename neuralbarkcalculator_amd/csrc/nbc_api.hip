@@ -414,8 +414,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         break;
       case OP_CONV: {
         int tile = c->conv_tile;
-        if (tile < 0 || o.Co % conv_tile_cols(tile) != 0 || (tile >= 7 && c->layout.convs[o.unit].stem))
-          tile = o.tile;                                  // override does not fit this layer: planned tile
+        if (tile < 0 || o.Co % conv_tile_cols(tile) != 0) tile = o.tile;   // override does not fit: planned tile
         rc = launch_conv_op(c, o, N, c->conv_impl, tile, s, &e);
         if (rc != NBC_OK) return rc;
         break;
@@ -501,7 +500,6 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
     int best = o.tile;
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
       if (o.Co % conv_tile_cols(tile) != 0) continue;
-      if (tile >= 7 && c->layout.convs[o.unit].stem) continue;   // ping-pong variants: non-stem only
       hipError_t e = hipSuccess;
       rc = launch_conv_op(c, o, N, 1, tile, s, &e);                       // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
