@@ -267,6 +267,12 @@ def main():
                                                    % (os.path.basename(pmc), t["algorithmic_bytes_per_launch"]))
             except (OSError, KeyError, ValueError):
                 pass
+        # layer-wise roofline of the whole step: every launch at max(MFMA time, HBM time) of its
+        # algorithmic FLOPs / bytes (0.649 ms per bf16 image with 6.29 TB/s)
+        hbm = 6.29e12
+        bound_s = sum(max(r["flops"] / (PEAK_TFLOPS[args.precision] * 1e12), r["bytes"] / hbm) for r in records)
+        out["roofline"]["layerwise_bound_ms_per_step"] = 1e3 * bound_s
+        out["roofline"]["layerwise_frac_timed_region"] = bound_s / (dt / args.steps)
         worst = sorted(records, key=lambda r: -r["ms"])[:6]
         out["top_ops"] = [{"name": r["name"], "ms": round(r["ms"], 4),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 else 0} for r in worst]

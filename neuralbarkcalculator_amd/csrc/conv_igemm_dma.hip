@@ -437,6 +437,8 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch)
 //   5   128x256   2x4            64x64      3       144 KiB  1
 //   6   256x64    4x2            64x32      3       120 KiB  1
+//   7   128x64    2x2            64x32      2       48 KiB   3   (short-K layers: K fits two stages)
+//   8   64x128    1x4            64x32      2       48 KiB   3
 template <int PREC, bool STEM>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
@@ -447,12 +449,14 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM>(a, s);
     case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM>(a, s);
     case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM>(a, s);
+    case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM>(a, s);
+    case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128};
 
 }  // namespace
 

@@ -33,7 +33,7 @@ struct ConvArgs {
 hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
 
 // v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co).
-constexpr int CONV_TILE_COUNT = 7;   // tile menu: see launch_tile() in conv_igemm_dma.hip
+constexpr int CONV_TILE_COUNT = 9;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 int choose_conv_tile(int M, int Co);
