@@ -508,18 +508,18 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   6   256x64    4x2            64x32      3       120 KiB  1
 //   7   128x64    2x2            64x32      2       48 KiB   3   (short-K layers: K fits two stages)
 //   8   64x128    1x4            64x32      2       48 KiB   3
-template <int PREC, bool STEM>
+template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
-    case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM>(a, s);
-    case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM>(a, s);
-    case 2: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM>(a, s);
-    case 3: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM>(a, s);
-    case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM>(a, s);
-    case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM>(a, s);
-    case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM>(a, s);
-    case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM>(a, s);
-    case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM>(a, s);
+    case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);
+    case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);
+    case 2: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, VAR>(a, s);
+    case 3: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, VAR>(a, s);
+    case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM, VAR>(a, s);
+    case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, VAR>(a, s);
+    case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, VAR>(a, s);
+    case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM, VAR>(a, s);
+    case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM, VAR>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -560,20 +560,21 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   if (tile < 0 || tile >= CONV_TILE_COUNT || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
   // NBC_CONV_ABLATE=1 (no MFMA) / 2 (no refill DMA): timing-only builds of the bf16 256x256 and
   // 128x256 tiles, results are garbage.  Never set outside an experiment.
-  // NBC_CONV_MFMA32=1: A/B build of the bf16 path on v_mfma_f32_32x32x16_bf16 (tiles 2, 3, 5)
-  static const int mfma32 = [] { const char* e = getenv("NBC_CONV_MFMA32"); return e ? atoi(e) : 0; }();
-  if (mfma32 && precision == 1 && !a.stem && (tile == 2 || tile == 3 || tile == 5)) {
-    if (tile == 2) return launch_cfg<1, 4, 2, 2, 2, 3, false, 1>(a, s);
-    if (tile == 3) return launch_cfg<1, 2, 4, 4, 2, 2, false, 1>(a, s);
-    return launch_cfg<1, 2, 4, 2, 2, 3, false, 1>(a, s);
-  }
   static const int ablate = [] { const char* e = getenv("NBC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
   if (ablate && precision == 1 && !a.stem && (tile == 3 || tile == 5)) {
     if (ablate == 1) return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 3>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 3>(a, s);
     return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 4>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 4>(a, s);
   }
-  if (precision == 0) return a.stem ? launch_tile<0, true>(a, tile, s) : launch_tile<0, false>(a, tile, s);
-  return a.stem ? launch_tile<1, true>(a, tile, s) : launch_tile<1, false>(a, tile, s);
+  if (precision == 0) return a.stem ? launch_tile<0, true, 0>(a, tile, s) : launch_tile<0, false, 0>(a, tile, s);
+  if (a.stem) return launch_tile<1, true, 0>(a, tile, s);
+  // bf16: the MFMA-heavy layers run on v_mfma_f32_16x16x32_bf16 (VAR 0: +4-5 % measured on the
+  // head and layer4 3x3 convs, the chip holds a higher clock on it); the residual 1x1 layers keep
+  // v_mfma_f32_32x32x16_bf16 (VAR 1), whose fragment registers leave room for the identity prefetch
+  // on the 256x256 tile.  The choice depends on the layer only, never on the tile, so the
+  // tile-invariance of the results holds.  NBC_CONV_MFMA32=1 forces VAR 1 everywhere (A/B runs).
+  static const int mfma32 = [] { const char* e = getenv("NBC_CONV_MFMA32"); return e ? atoi(e) : 0; }();
+  if (a.res != nullptr || mfma32) return launch_tile<1, false, 1>(a, tile, s);
+  return launch_tile<1, false, 0>(a, tile, s);
 }
 
 }  // namespace nbc
