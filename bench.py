@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--dump-ops", default=None, help="write the per-launch records (JSON) to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="skip the short fp32 parity-mode leg that is reported next to a bf16 run")
     ap.add_argument("--no-op-events", action="store_true", help="timed region without per-launch HIP events")
     return ap.parse_args()
 
@@ -286,9 +288,36 @@ def main():
             labels, counts = model.predict_labels(torch.from_numpy(frames[0])[None].to(dev))
             torch.cuda.synchronize()
             mism = int((labels.cpu() != labels_ref).sum())
-            out["parity"] = {"frame": "synthetic frame 0 (rank 0)", "label_mismatches": mism,
+            logits_ref = ref[2]
+            top2 = torch.topk(logits_ref, 2, dim=1).values
+            margin = (top2[:, 0] - top2[:, 1])
+            bad = labels.cpu() != labels_ref
+            out["parity"] = {"frame": "synthetic frame 0 (rank 0)", "precision": args.precision, "label_mismatches": mism,
                              "pixels": int(labels_ref.numel()), "label_match": 1.0 - mism / labels_ref.numel(),
-                             "oracle_class_counts": ref[1][0].tolist(), "gpu_class_counts": counts[0].cpu().tolist()}
+                             "oracle_class_counts": ref[1][0].tolist(), "gpu_class_counts": counts[0].cpu().tolist(),
+                             "oracle_logit_range": float(logits_ref.abs().max()),
+                             "max_oracle_margin_at_mismatch": float(margin[bad].max()) if mism else 0.0}
+            if args.precision != "fp32" and not args.no_fp32_leg:
+                # the exact-parity mode of the same library, same frame, same weights: its label match
+                # and its own throughput (one stream, latency-tuned tiles), reported beside the bf16 run
+                m32 = FCNResNet50("fp32").load_state_dict(sd).to(dev)
+                x32 = torch.from_numpy(frames[0])[None].to(dev)
+                m32.autotune(x32, objective="latency")
+                l32, c32 = m32.predict_labels(x32)
+                torch.cuda.synchronize()
+                n32 = 20
+                t0 = time.perf_counter()
+                for _ in range(n32):
+                    m32.predict_labels(x32, labels_dtype=torch.uint8)
+                torch.cuda.synchronize()
+                dt32 = time.perf_counter() - t0
+                bad32 = l32.cpu() != labels_ref
+                out["fp32_parity_mode"] = {"value": n32 / dt32, "unit": "images/s", "label_mismatches": int(bad32.sum()),
+                                           "label_match": 1.0 - int(bad32.sum()) / labels_ref.numel(),
+                                           "max_oracle_margin_at_mismatch": float(margin[bad32].max()) if int(bad32.sum()) else 0.0,
+                                           "gpu_class_counts": c32[0].cpu().tolist(),
+                                           "note": "v_mfma_f32_32x32x2_f32 path, batch 1, one stream, %d steps" % n32}
+                del m32
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
