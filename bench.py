@@ -279,6 +279,8 @@ def main():
         out["top_ops"] = [{"name": r["name"], "ms": round(r["ms"], 4),
                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["ms"] > 0 else 0} for r in worst]
 
+    if world > 1:                      # CPU baseline, parity and the fp32 leg are N=1 business
+        args.no_cpu_baseline = args.no_parity = True
     if not args.no_cpu_baseline or not args.no_parity:
         base, ref = cpu_baseline(sd, frames[0])
         if not args.no_cpu_baseline:
