@@ -272,12 +272,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
 template <int PREC, int BN, bool STEM>
 hipError_t launch_one(const ConvArgs& a, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0;     // bit d: attribute set on device d
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
+  if (!((attr_done >> dev) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<PREC, BN, STEM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_done |= 1ull << dev;
   }
   const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
   hipLaunchKernelGGL((conv_igemm_kernel<PREC, BN, STEM>), dim3(tiles), dim3(THREADS), smem, s, a);

@@ -483,13 +483,15 @@ template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int smem = S * (BM + BN) * 128 + 2048;     // ring + scale/shift table
-  static bool attr_set = false;
+  static unsigned long long attr_done = 0;     // bit d: attribute set on device d (one context per device)
   auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
-  if (!attr_set) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
+  if (!((attr_done >> dev) & 1ull)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_done |= 1ull << dev;
   }
   if (a.Co % BN != 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
