@@ -7,8 +7,9 @@ accelerated model call:
 * input  ``ROOT/samples/<wood_type>/*.{bmp,png,...}``; wood types and order of ``dataset.py:50-58``
   (``epinette_gelee, epinette_non_gelee, sapin``; file names sorted; ``"bmp" -> "png"`` in the
   output name, every occurrence, like ``str.replace`` there);
-* ``ROOT/processed/samples/<wood_type>/<name>.png`` (``models.py:173-203``; the 4096->1024 spline
-  resize is NOT built -- SURVEY.md row N4 -- so images larger than 1024 raise; ``trim_black`` is);
+* ``ROOT/processed/samples/<wood_type>/<name>.png`` (``models.py:173-203``: the bicubic resize to
+  1024 x 1024 of larger images, ``trim_black`` on square ones; host-side numpy, pinned by
+  scikit-image 0.18.3 fixtures);
 * ``ROOT/results/outputs/<wood_type>/<name>.png``: uint8 {0,127,255} mode 'L' (``models.py:349-356``);
 * ``ROOT/results/final_stats.csv``: tab separated, the reference's 7-name header and 6-value rows
   (``models.py:252-255,315-332,360-364``: ``img_size`` is dropped by the re-initialisation at
@@ -74,20 +75,64 @@ def trim_black(image: np.ndarray) -> np.ndarray:
     return image[first:last]
 
 
+def _cubic(x, f0, f1, f2, f3):
+    """scikit-image's cubic_interpolation (Catmull-Rom, a = -0.5): values at -1, 0, 1, 2; x in [0, 1]."""
+    return f1 + 0.5 * x * (f2 - f0 + x * (2.0 * f0 - 5.0 * f1 + 4.0 * f2 - f3 + x * (3.0 * (f1 - f2) + f3 - f0)))
+
+
+def _reflect(i: np.ndarray, n: int) -> np.ndarray:
+    """numpy.pad 'reflect' indexing (mirror without repeating the edge)."""
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * (n - 1)
+    i = np.mod(i, period)
+    return np.where(i >= n, period - i, i)
+
+
+def resize_bicubic_reflect(image: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """``skimage.transform.resize(image, (out_h, out_w), order=3, mode='reflect',
+    anti_aliasing=False)`` (models.py:194-198) for a float HWC image: output pixel i samples the
+    input at ``factor * (i + 0.5) - 0.5`` with a separable 4-tap Catmull-Rom kernel in the image's
+    own float type, reflected borders, result clipped to the input range (``clip=True``).  Pinned by
+    scikit-image 0.18.3 fixtures (tests/golden/preprocess_*.npz)."""
+    h, w = image.shape[:2]
+    dt = image.dtype if image.dtype in (np.float32, np.float64) else np.float64
+    img = image.astype(dt, copy=False)
+    ry = (h / out_h) * (np.arange(out_h) + 0.5) - 0.5
+    rx = (w / out_w) * (np.arange(out_w) + 0.5) - 0.5
+    y0 = np.floor(ry).astype(np.int64)
+    x0 = np.floor(rx).astype(np.int64)
+    ty = (ry - y0).astype(dt).reshape(-1, 1, 1)
+    tx = (rx - x0).astype(dt).reshape(1, -1, 1)
+    cols = [_reflect(x0 + k - 1, w) for k in range(4)]
+    fr = []
+    for k in range(4):
+        rows = img[_reflect(y0 + k - 1, h)]
+        fr.append(_cubic(tx, *[rows[:, c] for c in cols]))
+    out = _cubic(ty, *fr)
+    return np.clip(out, img.min(), img.max()).astype(dt, copy=False)
+
+
+def preprocess_image(img_u8: np.ndarray, target_size: int = 1024) -> np.ndarray:
+    """models.py:191-203 for one decoded RGB image: ToTensor (u8 -> float32 / 255), resize to
+    ``target_size`` x ``target_size`` when either side is larger, ``trim_black`` when square,
+    float -> uint8 like ``skimage.io.imsave`` (``rint(x * 255)``)."""
+    image = img_u8.astype(np.float32) / np.float32(255)
+    if max(image.shape[:2]) > target_size:
+        image = resize_bicubic_reflect(image, target_size, target_size)
+    if image.shape[0] == image.shape[1]:
+        image = trim_black(image)
+    return np.clip(np.rint(image * 255.0), 0, 255).astype(np.uint8)
+
+
 def preprocess_images(root: str, target_size: int = 1024) -> None:
-    """models.py:173-203 without the spline resize (row N4): RGB decode, trim_black on square
-    images, save as PNG under processed/."""
+    """models.py:173-203: decode, resize / trim, save as PNG under processed/."""
     from PIL import Image
     for path, name, wood in list_images(root):
         with open(path, "rb") as f:
             img = np.asarray(Image.open(f).convert("RGB"))                 # dataset.py:82-90
-        if max(img.shape[:2]) > target_size:
-            raise NotImplementedError(
-                f"{path}: {img.shape[1]}x{img.shape[0]} needs the 4096->1024 resize of models.py:194-198, "
-                "which is outside the accelerated path (SURVEY.md N4); resize it first")
-        if img.shape[0] == img.shape[1]:
-            img = (trim_black(img.astype(np.float32) / 255.0) * 255.0 + 0.5).astype(np.uint8)
-        Image.fromarray(img, mode="RGB").save(os.path.join(root, "processed", "samples", wood, name))
+        out = preprocess_image(img, target_size)
+        Image.fromarray(out, mode="RGB").save(os.path.join(root, "processed", "samples", wood, name))
 
 
 def shard_indices(n: int, rank: int, world: int) -> List[int]:
