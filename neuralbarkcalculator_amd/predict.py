@@ -75,9 +75,14 @@ def trim_black(image: np.ndarray) -> np.ndarray:
     return image[first:last]
 
 
-def _cubic(x, f0, f1, f2, f3):
-    """scikit-image's cubic_interpolation (Catmull-Rom, a = -0.5): values at -1, 0, 1, 2; x in [0, 1]."""
-    return f1 + 0.5 * x * (f2 - f0 + x * (2.0 * f0 - 5.0 * f1 + 4.0 * f2 - f3 + x * (3.0 * (f1 - f2) + f3 - f0)))
+def _cubic(x, f0, f1, f2, f3, dt=np.float64):
+    """scikit-image's cubic_interpolation (Catmull-Rom, a = -0.5): values at -1, 0, 1, 2; x in [0, 1].
+    C evaluation rules of its Cython source for an image of float type ``dt``: the two differences of
+    image values are taken in ``dt``, everything that meets a (double) literal in double."""
+    d20 = (f2.astype(dt) - f0.astype(dt)).astype(np.float64)
+    d12 = (f1.astype(dt) - f2.astype(dt)).astype(np.float64)
+    f0, f1, f2, f3 = (f.astype(np.float64) for f in (f0, f1, f2, f3))
+    return f1 + 0.5 * x * (d20 + x * (2.0 * f0 - 5.0 * f1 + 4.0 * f2 - f3 + x * (3.0 * d12 + f3 - f0)))
 
 
 def _reflect(i: np.ndarray, n: int) -> np.ndarray:
@@ -98,31 +103,35 @@ def resize_bicubic_reflect(image: np.ndarray, out_h: int, out_w: int) -> np.ndar
     h, w = image.shape[:2]
     dt = image.dtype if image.dtype in (np.float32, np.float64) else np.float64
     img = image.astype(dt, copy=False)
-    ry = (h / out_h) * (np.arange(out_h) + 0.5) - 0.5
-    rx = (w / out_w) * (np.arange(out_w) + 0.5) - 0.5
+    # scikit-image's _warp_fast works in the image's float type (float32 after ToTensor): sample
+    # coordinates and the two fractional offsets are rounded to it; each cubic_interpolation call
+    # evaluates in double (its literals are doubles) and returns the image's type.
+    ry = ((h / out_h) * (np.arange(out_h) + 0.5) - 0.5).astype(dt)
+    rx = ((w / out_w) * (np.arange(out_w) + 0.5) - 0.5).astype(dt)
     y0 = np.floor(ry).astype(np.int64)
     x0 = np.floor(rx).astype(np.int64)
-    ty = (ry - y0).astype(dt).reshape(-1, 1, 1)
-    tx = (rx - x0).astype(dt).reshape(1, -1, 1)
+    ty = (ry - y0.astype(dt)).astype(np.float64).reshape(-1, 1, 1)
+    tx = (rx - x0.astype(dt)).astype(np.float64).reshape(1, -1, 1)
     cols = [_reflect(x0 + k - 1, w) for k in range(4)]
     fr = []
     for k in range(4):
         rows = img[_reflect(y0 + k - 1, h)]
-        fr.append(_cubic(tx, *[rows[:, c] for c in cols]))
-    out = _cubic(ty, *fr)
-    return np.clip(out, img.min(), img.max()).astype(dt, copy=False)
+        fr.append(_cubic(tx, *[rows[:, c] for c in cols], dt=dt).astype(dt))
+    out = _cubic(ty, *fr, dt=dt).astype(dt)
+    return np.clip(out, img.min(), img.max())
 
 
 def preprocess_image(img_u8: np.ndarray, target_size: int = 1024) -> np.ndarray:
     """models.py:191-203 for one decoded RGB image: ToTensor (u8 -> float32 / 255), resize to
     ``target_size`` x ``target_size`` when either side is larger, ``trim_black`` when square,
-    float -> uint8 like ``skimage.io.imsave`` (``rint(x * 255)``)."""
+    float -> uint8 like ``skimage.io.imsave`` does through imageio (``uint8(float64(x) * 255 + 0.499999999)``:
+    the "Lossy conversion from float32 to uint8" path, which rounds exact halves down)."""
     image = img_u8.astype(np.float32) / np.float32(255)
     if max(image.shape[:2]) > target_size:
         image = resize_bicubic_reflect(image, target_size, target_size)
     if image.shape[0] == image.shape[1]:
         image = trim_black(image)
-    return np.clip(np.rint(image * 255.0), 0, 255).astype(np.uint8)
+    return np.clip(image.astype(np.float64) * 255.0 + 0.499999999, 0, 255).astype(np.uint8)
 
 
 def preprocess_images(root: str, target_size: int = 1024) -> None:

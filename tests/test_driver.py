@@ -57,9 +57,11 @@ def test_preprocessor_matches_skimage_fixture(path):
     out = drv.preprocess_image(g["image"], int(g["target"]))
     assert out.shape == g["expected"].shape and out.dtype == np.uint8
     diff = np.abs(out.astype(np.int16) - g["expected"].astype(np.int16))
-    # float32 interpolation in a different operation order: a value that lands on x.5 may round the
-    # other way; never more than one grey level, and rarely
-    assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (int(diff.max()), float((diff > 0).mean()))
+    # Every remaining difference sits on an exact tie: with integer zoom factors the taps are
+    # (-1, 9, 9, -1)/16, so an interpolated value lands on k + 0.5 for ~1/16 of the pixels of a random
+    # image, and float32 rounding noise in the C evaluation decides which way it goes.  Never more
+    # than one grey level.
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-2, (int(diff.max()), float((diff > 0).mean()))
 
 
 def test_preprocess_images_resizes_oversize_inputs(tmp_path):
