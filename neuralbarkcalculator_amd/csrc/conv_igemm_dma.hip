@@ -164,43 +164,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       a_inc[i] = ok ? 128 : 0;
     }
   };
-  if constexpr (!STEM && VAR != 5) set_tap(0, 0);
-
-  // ---- K order "channel block outer, taps inner" (VAR 5).  In tap-major order a 3x3 layer comes
-  // back to the same input line (through a vertical neighbour's tap) a third of the K loop later,
-  // long after the 4 MiB L2 has dropped it: measured fabric traffic of the head conv was 7.3x its
-  // algorithmic bytes.  With the taps innermost all nine reads of a line fall within nine K-steps.
-  // Per row: the pointer to (iy0 + kh*dil, ix0) for each kh, and validity bits (bit kh: row inside
-  // the image, bit 4+kw: column inside); a K-step then needs one select and one add per row.
-  constexpr bool CBM = (!STEM && VAR == 5);
-  const unsigned char* a_row[CBM ? A_PASSES : 1][3];
-  unsigned a_okbits[CBM ? A_PASSES : 1];
-  if constexpr (CBM) {
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      unsigned bits = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int iy = a_iy0[i] + k * p.dil, ix = a_ix0[i] + k * p.dil;
-        if (k < p.KH && (unsigned)iy < (unsigned)p.Hi) bits |= 1u << k;
-        if (k < p.KW && (unsigned)ix < (unsigned)p.Wi) bits |= 16u << k;
-        a_row[i][k] = xb + (long long)(a_img[i] + iy * p.Wi + a_ix0[i]) * pix_bytes + a_coff[i];
-      }
-      a_okbits[i] = bits;
-    }
-  }
-  const int kw_stride = p.dil * pix_bytes;           // bytes between horizontally adjacent taps
+  if constexpr (!STEM) set_tap(0, 0);
 
   // DMA d (0..L-1: activation passes first, then weight passes) of K-step t into ring slot `stage`.
   auto issue_one = [&](int d, int t, unsigned sa) {
     if (d < A_PASSES) {
       const int i = d;
-      if constexpr (CBM) {
-        const unsigned char* base = ld_kh == 0 ? a_row[i][0] : (ld_kh == 1 ? a_row[i][1] : a_row[i][2]);
-        const bool ok = ((a_okbits[i] >> ld_kh) & (a_okbits[i] >> (4 + ld_kw)) & 1u) != 0;
-        const unsigned char* src = ok ? base + (ld_kw * kw_stride + ld_cb * 128) : zpage;
-        dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
-      } else if constexpr (!STEM) {
+      if constexpr (!STEM) {
         dma16(a_ptr[i], sa + (unsigned)(ROWS_PER_PASS * 128 * i));
         a_ptr[i] += a_inc[i];
       } else {
@@ -214,12 +184,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       }
     } else {
       const int i = d - A_PASSES;
-      if constexpr (CBM) {        // packed rows stay [tap][channel]: K-step (cb, tap) sits at (tap*cblocks + cb)*128
-        dma16(wsrc[i] + ((ld_kh * p.KW + ld_kw) * cblocks + ld_cb) * 128, sa + (unsigned)(A_BYTES + ROWS_PER_PASS * 128 * i));
-      } else {
-        dma16(wsrc[i], sa + (unsigned)(A_BYTES + ROWS_PER_PASS * 128 * i));
-        wsrc[i] += 128;
-      }
+      dma16(wsrc[i], sa + (unsigned)(A_BYTES + ROWS_PER_PASS * 128 * i));
+      wsrc[i] += 128;
     }
   };
   // The L DMAs of a K-step are issued in four parts so that the main loop can slot one part behind
@@ -230,14 +196,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 #pragma unroll
     for (int d = 0; d < L; ++d)
       if (d * 4 / L == part) issue_one(d, t, sa);
-    if constexpr (CBM) {
-      if (part == 3) {                               // wave-uniform: taps innermost
-        if (++ld_kw == p.KW) {
-          ld_kw = 0;
-          if (++ld_kh == p.KH) { ld_kh = 0; ++ld_cb; }
-        }
-      }
-    } else if constexpr (!STEM) {
+    if constexpr (!STEM) {
       if (part == 3) {
         if (++ld_cb == cblocks) {                  // wave-uniform: next K-step starts a new tap
           ld_cb = 0;
@@ -258,7 +217,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // bf16 uses v_mfma_f32_16x16x32_bf16 (VAR 0): same cycles per FLOP as 32x32x16 but the chip holds a
   // higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7); VAR 1 keeps the
   // 32x32x16 form for A/B runs.  f32 always uses 32x32x2.
-  constexpr bool M16 = (PREC == 1 && (VAR == 0 || VAR == 4 || VAR == 5));
+  constexpr bool M16 = (PREC == 1 && (VAR == 0 || VAR == 4));
   constexpr int MT16 = 2 * MT, NT16 = 2 * NT;
   const int r16 = lane & 15, q16 = lane >> 4;
   f32x16 acc[M16 ? 1 : NT][M16 ? 1 : MT];
@@ -368,7 +327,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   constexpr int PASSES = 32 / PIX_PER_PASS;
   // identity prefetch: <= 64 VGPRs per lane, and not on the 128x64 wave tile of the 16x16 path
   // (128 accumulators + 48 fragment registers leave no room: it spilled)
-  constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && VAR != 1 && VAR != 3 && MT * NT >= 8);
+  constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && VAR != 1 && MT * NT >= 8);
   static_assert(WM * WN * 32 * PITCH <= S * STAGE_BYTES, "epilogue scratch must fit in the ring");
   unsigned char* yb = static_cast<unsigned char*>(p.y);
   const unsigned char* resb = static_cast<const unsigned char*>(p.res);
@@ -616,9 +575,6 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   // on the 256x256 tile.  The choice depends on the layer only, never on the tile, so the
   // tile-invariance of the results holds.  NBC_CONV_MFMA32=1 forces VAR 1 everywhere (A/B runs).
   static const int mfma32 = [] { const char* e = getenv("NBC_CONV_MFMA32"); return e ? atoi(e) : 0; }();
-  // NBC_CONV_KORDER=1: A/B build with the K loop ordered channel-block outer / taps inner (bf16, KxK)
-  static const int korder = [] { const char* e = getenv("NBC_CONV_KORDER"); return e ? atoi(e) : 0; }();
-  if (korder && a.KH * a.KW > 1) return launch_tile<1, false, 5>(a, tile, s);
   if (a.res != nullptr || mfma32) return launch_tile<1, false, 1>(a, tile, s);
   return launch_tile<1, false, 0>(a, tile, s);
 }
