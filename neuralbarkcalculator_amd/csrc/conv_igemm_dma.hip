@@ -191,7 +191,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // The L DMAs of a K-step are issued in four parts so that the main loop can slot one part behind
   // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
   auto issue_part = [&](int part, int t, int stage) {
-    if constexpr (VAR == 4) return;                  // timing-only ablation: no refill DMAs in the loop
+    if constexpr (VAR == 4 || VAR == 7) return;      // timing-only ablations: no refill DMAs in the loop
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
 #pragma unroll
     for (int d = 0; d < L; ++d)
@@ -243,6 +243,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   auto compute = [&](int stage, bool do_issue, int t_issue, int issue_stage) {
     const unsigned char* sa = smem + stage * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
+    if constexpr (VAR == 6) {                        // timing-only ablation: DMA + barriers only
+      if (do_issue) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(part, t_issue, issue_stage);
+      }
+      return;
+    }
     if constexpr (M16) {
       // two 32-deep halves per K-step; lane (r16, q16) reads row r16 of each 16-row tile, chunk 4*half+q16
       constexpr bool DBUF = (MT16 + NT16) * 8 <= 64;      // both halves' fragments in <= 64 VGPRs
@@ -285,10 +292,20 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
       for (int j = 0; j < NT; ++j)
         wfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
     };
-    load_frags(0, pf[0], wf[0]);
+    if constexpr (VAR == 7) {                        // timing-only ablation: MFMAs on constant fragments
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) pf[b][i] = make_uint4(0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[b][j] = make_uint4(0x3f803f80u, 0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u);
+      }
+    } else {
+      load_frags(0, pf[0], wf[0]);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks + 1 < 4) load_frags(ks + 1, pf[(ks + 1) & 1], wf[(ks + 1) & 1]);
+      if (VAR != 7 && ks + 1 < 4) load_frags(ks + 1, pf[(ks + 1) & 1], wf[(ks + 1) & 1]);
       if constexpr (VAR == 3) {                        // timing-only ablation: fragments read, no MFMA
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   constexpr int PASSES = 32 / PIX_PER_PASS;
   // identity prefetch: <= 64 VGPRs per lane, and not on the 128x64 wave tile of the 16x16 path
   // (128 accumulators + 48 fragment registers leave no room: it spilled)
-  constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && VAR != 1 && MT * NT >= 8);
+  constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && (VAR == 0 || VAR == 4) && MT * NT >= 8);
   static_assert(WM * WN * 32 * PITCH <= S * STAGE_BYTES, "epilogue scratch must fit in the ring");
   unsigned char* yb = static_cast<unsigned char*>(p.y);
   const unsigned char* resb = static_cast<const unsigned char*>(p.res);
@@ -564,8 +581,14 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   // 128x256 tiles, results are garbage.  Never set outside an experiment.
   static const int ablate = [] { const char* e = getenv("NBC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
   if (ablate && precision == 1 && !a.stem && (tile == 3 || tile == 5)) {
-    if (ablate == 1) return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 3>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 3>(a, s);
-    return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 4>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 4>(a, s);
+    // 1: no MFMA (DMA + fragment reads)  2: no refill DMA (MFMA + fragment reads)
+    // 3: DMA + barriers only             4: MFMA on constant fragments, no DMA, no fragment reads
+    switch (ablate) {
+      case 1: return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 3>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 3>(a, s);
+      case 2: return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 4>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 4>(a, s);
+      case 3: return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 6>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 6>(a, s);
+      default: return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 7>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 7>(a, s);
+    }
   }
   if (precision == 0) return a.stem ? launch_tile<0, true, 0>(a, tile, s) : launch_tile<0, false, 0>(a, tile, s);
   if (a.stem) return launch_tile<1, true, 0>(a, tile, s);
