@@ -148,8 +148,7 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
                         float* logits_full_dev, void* labels_dev, int labels_dtype,
                         int64_t* counts_dev, int exclude_nodes, void* hip_stream);
 
-/* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring plus the row-strip kernel on
- * the 3x3 stride-1 layers whose shape allows it (default), 2 = LDS-DMA ring only, 0 = the
+/* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
  * register-staged reference kernel; tile = -1 (per-layer choice) or 0..8 = 128x64, 128x128,
  * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128 (pixels x channels) forced wherever the
  * layer's Cout allows it. */

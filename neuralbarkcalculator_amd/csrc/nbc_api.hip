@@ -223,7 +223,6 @@ int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream
   ConvArgs a{};
   a.x = c->bufs[o.in_buf];
   a.w = c->weights + pc.w_off;
-  a.w_strip = pc.w_strip_off ? c->weights + pc.w_strip_off : nullptr;
   a.scale = reinterpret_cast<const float*>(c->weights + pc.scale_off);
   a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
   a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
@@ -246,9 +245,7 @@ int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream
     return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
   a.x_bytes = (unsigned)xb;
   a.w_bytes = (unsigned)wbts;
-  if (impl == 0) *err = launch_conv_igemm(a, prec, s);
-  else if (impl == 1 && strip_eligible(a, prec)) *err = launch_conv3x3_strip(a, prec, s);   // by shape only
-  else *err = launch_conv_dma(a, prec, tile, s);
+  *err = impl == 0 ? launch_conv_igemm(a, prec, s) : launch_conv_dma(a, prec, tile, s);
   return NBC_OK;
 }
 
@@ -344,7 +341,7 @@ int nbc_set_normalization(nbc_ctx* c, const float mean[3], const float stdv[3]) 
 
 int nbc_set_conv_impl(nbc_ctx* c, int impl, int tile) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
-  if (impl < 0 || impl > 2) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: impl must be 0, 1 or 2");
+  if (impl != 0 && impl != 1) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: impl must be 0 or 1");
   if (tile < -1 || tile >= CONV_TILE_COUNT) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: bad tile id");
   c->conv_impl = impl;
   c->conv_tile = tile;
@@ -504,10 +501,10 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
       if (o.Co % conv_tile_cols(tile) != 0) continue;
       hipError_t e = hipSuccess;
-      rc = launch_conv_op(c, o, N, 2, tile, s, &e);                       // warm-up (and attribute set-up)
+      rc = launch_conv_op(c, o, N, 1, tile, s, &e);                       // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
       (void)hipEventRecord(e0, s);
-      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, N, 2, tile, s, &e);
+      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, N, 1, tile, s, &e);
       (void)hipEventRecord(e1, s);
       if (hipEventSynchronize(e1) != hipSuccess) continue;
       float ms = 0.f;

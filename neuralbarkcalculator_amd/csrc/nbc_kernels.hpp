@@ -11,7 +11,6 @@ namespace nbc {
 struct ConvArgs {
   const void* x;        // [N][Hi][Wi][Ci] elements
   const void* w;        // [Co][ksteps*128 bytes]
-  const void* w_strip;  // nullable: 3x3 weights in (kh, channel block, kw) order for conv3x3_strip.hip
   const float* scale;   // [Co]
   const float* shift;   // [Co]
   const void* res;      // nullable, [M][Co] elements (the identity of a bottleneck)
@@ -39,10 +38,6 @@ int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 int choose_conv_tile(int M, int Co);
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
-
-// 3x3 stride-1 layers with an LDS-resident input row strip (conv3x3_strip.hip); shape test first.
-bool strip_eligible(const ConvArgs& a, int precision);
-hipError_t launch_conv3x3_strip(const ConvArgs& a, int precision, hipStream_t s);
 
 // float32 NCHW [N,3,H,W] -> NHWC elements padded to 16 bytes per pixel.
 hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int precision, hipStream_t s);

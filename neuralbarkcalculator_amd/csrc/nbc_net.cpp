@@ -127,18 +127,6 @@ PackedLayout packed_layout(int precision) {
     }
     L.convs.push_back(p);
   }
-  // second copy of the 3x3 stride-1 weights in (kh, channel block, kw) order, behind everything else
-  {
-    const auto& units = conv_units();
-    for (size_t i = 0; i < units.size(); ++i) {
-      const ConvUnit& c = units[i];
-      L.convs[i].w_strip_off = 0;
-      if (c.k == 3 && c.stride == 1 && c.cin >= 64) {
-        L.convs[i].w_strip_off = off;
-        off = align_up(off + (size_t)c.cout * L.convs[i].ksteps * kKStepBytes, 256);
-      }
-    }
-  }
   L.total_bytes = off;
   return L;
 }
@@ -264,19 +252,6 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
             if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;
             else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
           }
-    }
-    if (p.w_strip_off) {     // same values, K order (kh, channel block, kw): what conv3x3_strip.hip walks
-      const int cblocks = c.cin * eb / kKStepBytes;
-      const int epb = kKStepBytes / eb;                    // elements per 128-byte block
-      for (int o = 0; o < c.cout; ++o) {
-        const unsigned char* src = base + p.w_off + (size_t)o * row_bytes;
-        unsigned char* dst = base + p.w_strip_off + (size_t)o * row_bytes;
-        for (int kh = 0; kh < 3; ++kh)
-          for (int cb = 0; cb < cblocks; ++cb)
-            for (int kw = 0; kw < 3; ++kw)
-              std::memcpy(dst + ((size_t)(kh * cblocks + cb) * 3 + kw) * kKStepBytes,
-                          src + ((size_t)(kh * 3 + kw) * c.cin + (size_t)cb * epb) * eb, kKStepBytes);
-      }
     }
     // eval-mode BatchNorm as ATen applies it: alpha = gamma * invstd, beta = bias - mean * alpha
     const float* g = static_cast<const float*>(given[c.bn + ".weight"]->data);

@@ -45,8 +45,6 @@ struct PackedConv {
   int ksteps;            // K-steps of 128 bytes
   bool stem;             // one 16-byte chunk per tap (cin_pad*elem = 16 bytes)
   bool head;             // classifier.4: weights kept f32 [3][512], shift = bias
-  size_t w_strip_off;    // 3x3 stride-1 units: second copy [cout][kh][cblock][kw][128 B] for the
-                         // row-strip kernel (conv3x3_strip.hip); 0 when the unit has none
 };
 
 struct PackedLayout {

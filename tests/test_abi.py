@@ -133,18 +133,6 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
         inv = np.float32(1.0) / np.sqrt(var + np.float32(1e-5), dtype=np.float32)
         np.testing.assert_array_equal(scale, g * inv)
         np.testing.assert_array_equal(shift, b - mu * (g * inv))
-    # behind the per-unit sections: a second copy of the 3x3 stride-1 weights in (kh, cblock, kw) order
-    for u in topology.conv_units():
-        if not (u.k == 3 and u.stride == 1 and u.cin >= 64):
-            continue
-        cblocks, epb = u.cin * eb // 128, 128 // eb
-        raw = blob[off: off + u.cout * 9 * cblocks * 128]
-        got = (raw.view(np.float32) if prec == 0 else _bf16_to_f32(raw.view(np.uint16))).reshape(u.cout, 3, cblocks, 3, epb)
-        want = sd_np[u.name + ".weight"].reshape(u.cout, cblocks, epb, 3, 3).transpose(0, 3, 1, 4, 2)   # [O][kh][cb][kw][c]
-        if prec == 1:
-            want = torch.from_numpy(np.ascontiguousarray(want)).to(torch.bfloat16).float().numpy()
-        np.testing.assert_array_equal(got, want, err_msg=u.name + " (strip copy)")
-        off = align(off + u.cout * 9 * cblocks * 128)
     assert off == blob.nbytes
 
 

@@ -250,7 +250,7 @@ def test_errors_are_python_exceptions(gpu_fp32):
         FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
 
 
-@pytest.mark.parametrize("impl,tile", [(0, -1), (2, -1)] + [(1, t) for t in range(9)])
+@pytest.mark.parametrize("impl,tile", [(0, -1)] + [(1, t) for t in range(9)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, impl, tile):
     """Each conv kernel instantiation (register-staged v1; LDS-DMA v2 at every tile shape) against
@@ -294,32 +294,3 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
         assert torch.equal(model(x), base)
     finally:
         model.set_conv_impl(1, -1)
-
-
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_row_strip_kernel_layers(oracle_model, gpu_fp32, gpu_bf16, mode):
-    """The 3x3 row-strip kernel (impl 1, every dilation incl. 4 at 32-wide maps, batch 2, a height that
-    leaves a partial last tile) layer by layer against the oracle, and against the generic kernel."""
-    from oracle.fcn_resnet50_oracle import layer_outputs
-    model = gpu_fp32 if mode == "fp32" else gpu_bf16
-    rtol = LAYER_RTOL_FP32 if mode == "fp32" else LAYER_RTOL_BF16
-    x = frames([15, 16], 232, 256)          # 29 x 32 maps at stride 8: R = 8 rows per tile, 29 = 3*8 + 5
-    ref = layer_outputs(oracle_model, x)
-    names = [n for n in ref if n.endswith(".conv2") or n == "classifier.0"]
-    got = {}
-    try:
-        for impl in (1, 2):
-            model.set_conv_impl(impl, -1)
-            model.set_keep_activations(True)
-            model.lowres_logits(x.to(DEV))
-            torch.cuda.synchronize()
-            got[impl] = {n: model.read_activation(n, ref[n].numel()) for n in names}
-    finally:
-        model.set_keep_activations(False)
-        model.set_conv_impl(1, -1)
-    for n in names:
-        want = ref[n].numpy()
-        scale = float(np.abs(want).max())
-        for impl in (1, 2):
-            err = float(np.abs(got[impl][n] - want).max())
-            assert err <= rtol * scale, f"{n} impl {impl}: max err {err} vs scale {scale} ({mode})"
