@@ -149,9 +149,10 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
                         int64_t* counts_dev, int exclude_nodes, void* hip_stream);
 
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
- * register-staged reference kernel; tile = -1 (per-layer choice) or 0..8 = 128x64, 128x128,
- * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128 (pixels x channels) forced wherever the
- * layer's Cout allows it. */
+ * register-staged reference kernel; tile = -1 (per-layer choice) or 0..11 = 128x64, 128x128,
+ * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave
+ * 128x128 and 128x64 and the 16-wave 256x128 (pixels x channels), forced wherever the layer's Cout
+ * allows it. */
 int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
 
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real

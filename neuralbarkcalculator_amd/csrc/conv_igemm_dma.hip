@@ -58,14 +58,38 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       : "memory");
 }
 
+// Diagnostic build (tools/conv_timeline.hip, -DNBC_STAMPS): thread 0 of every block writes the 100 MHz
+// wall clock at phase boundaries into a buffer nothing else reads.  The library build has no stamps.
+#ifdef NBC_STAMPS
+#define NBC_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define NBC_STAMP(i) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// LDS bytes of the ring (it also hosts the epilogue's per-wave transpose scratch, which is larger than
+// the ring on the 8-wave 128x128 tile); the scale/shift table sits right behind it.
+constexpr int ring_bytes(int prec, int wm, int wn, int mt, int nt, int s) {
+  const int ring = s * (wm * mt * 32 + wn * nt * 32) * 128;
+  const int scratch = wm * wn * 32 * (nt * 32 * 4 + 16);
+  return ring > scratch ? ring : scratch;
+}
+// Register budget: blocks of >= 8 waves whose LDS lets two of them share a CU are compiled for four
+// waves per SIMD (128 VGPRs), so that one block's epilogue overlaps the other's K loop.
+constexpr int min_waves_per_simd(int prec, int wm, int wn, int mt, int nt, int s) {
+  return (wm * wn >= 8 && (wm * wn >= 16 || ring_bytes(prec, wm, wn, mt, nt, s) + 2048 <= 80 * 1024)) ? 4 : 2;
+}
+
 // Tile = (WM*MT*32) pixels x (WN*NT*32) channels, WM*WN waves, S LDS stages.
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, NT, S)) void conv_dma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EB = PREC == 0 ? 4 : 2;
   constexpr int THREADS = WM * WN * 64;
@@ -74,6 +98,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   constexpr int A_BYTES = BM * 128;
   constexpr int B_BYTES = BN * 128;
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int TABLE_OFF = ring_bytes(PREC, WM, WN, MT, NT, S);      // scale/shift table behind ring and scratch
   constexpr int ROWS_PER_PASS = THREADS / 8;
   constexpr int A_PASSES = BM / ROWS_PER_PASS;
   constexpr int B_PASSES = BN / ROWS_PER_PASS;
@@ -84,6 +109,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  NBC_STAMP(0);                                     // block start
 
   // ---- tile coordinates (XCD-contiguous, n fastest; see conv_igemm.hip)
   const int tiles_n = p.Co / BN;
@@ -345,7 +371,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // identity prefetch: <= 64 VGPRs per lane, and not on the 128x64 wave tile of the 16x16 path
   // (128 accumulators + 48 fragment registers leave no room: it spilled)
   constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && (VAR == 0 || VAR == 4) && MT * NT >= 8);
-  static_assert(WM * WN * 32 * PITCH <= S * STAGE_BYTES, "epilogue scratch must fit in the ring");
+  static_assert(WM * WN * 32 * PITCH <= TABLE_OFF, "epilogue scratch must fit below the scale/shift table");
   unsigned char* yb = static_cast<unsigned char*>(p.y);
   const unsigned char* resb = static_cast<const unsigned char*>(p.res);
   const int o_pix = lane / CPR, o_chunk = lane % CPR;
@@ -369,23 +395,26 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
     }
   };
 
+  NBC_STAMP(8);                                     // address set-up done
   // ---- pipeline.  Steps beyond T issue nothing; the counted wait then over-waits, which is safe
   // (vmcnt retires in order), and the tail uses vmcnt(0).
   // First of all the block's BN scale/shift pairs go to a 2 KiB LDS table behind the ring (two
   // LDS-DMAs of wave 0, older than every ring DMA, so the first counted wait covers them): the
   // epilogue then reads them from LDS instead of paying an L2 round trip per 32-pixel slab.
   if (wave == 0 && lane < BN / 4) {
-    dma16(p.scale + n0 + lane * 4, smem_base + (unsigned)(S * STAGE_BYTES));
-    dma16(p.shift + n0 + lane * 4, smem_base + (unsigned)(S * STAGE_BYTES) + 1024u);
+    dma16(p.scale + n0 + lane * 4, smem_base + (unsigned)TABLE_OFF);
+    dma16(p.shift + n0 + lane * 4, smem_base + (unsigned)TABLE_OFF + 1024u);
   }
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
     if (s < T) issue_step(s, s);
+  NBC_STAMP(1);                                     // prologue DMAs issued
   for (int t = 0; t < T - 1; ++t) {
     // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
     if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    if (t == 0) NBC_STAMP(2);                       // first K-step landed
     // the ring slot of step t-1 is free from here on.  With three or more stages its refill (step
     // t+S-1) is issued in four parts, one behind each MFMA cluster of this step; with two stages the
     // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
@@ -400,6 +429,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // requested here and its HBM/MALL latency hides under the last MFMAs and the transposes below.
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
+  NBC_STAMP(3);                                     // last K-step landed (main loop done but for its MFMAs)
   prefetch_identity();
   compute((T - 1) % S, false, 0, 0);
 
@@ -411,6 +441,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
   // the way in, and on the way out every lane owns 16 output bytes of one pixel, so identity loads
   // and stores are whole 128-byte (bf16) / 256-byte (f32) row segments.
   __syncthreads();                                  // every wave has finished reading the ring
+  NBC_STAMP(4);                                     // MFMAs done, epilogue starts
   unsigned char* scr = smem + wave * (32 * PITCH);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -421,8 +452,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < NT16; ++j) {
           const int nl = j * 16 + 4 * q16;
-          const float4 sc = *reinterpret_cast<const float4*>(smem + S * STAGE_BYTES + (wn * SLAB_CH + nl) * 4);
-          const float4 sh = *reinterpret_cast<const float4*>(smem + S * STAGE_BYTES + 1024 + (wn * SLAB_CH + nl) * 4);
+          const float4 sc = *reinterpret_cast<const float4*>(smem + TABLE_OFF + (wn * SLAB_CH + nl) * 4);
+          const float4 sh = *reinterpret_cast<const float4*>(smem + TABLE_OFF + 1024 + (wn * SLAB_CH + nl) * 4);
           const f32x4 a = acc16[j][2 * i + i2];
           float4 v;
           v.x = __builtin_fmaf(a[0], sc.x, sh.x);
@@ -437,8 +468,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = j * 32 + 8 * g + 4 * h;      // channel inside the slab
-        const float4 sc = *reinterpret_cast<const float4*>(smem + S * STAGE_BYTES + (wn * SLAB_CH + nl) * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(smem + S * STAGE_BYTES + 1024 + (wn * SLAB_CH + nl) * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(smem + TABLE_OFF + (wn * SLAB_CH + nl) * 4);
+        const float4 sh = *reinterpret_cast<const float4*>(smem + TABLE_OFF + 1024 + (wn * SLAB_CH + nl) * 4);
         float4 v;
         v.x = __builtin_fmaf(acc[j][i][4 * g + 0], sc.x, sh.x);
         v.y = __builtin_fmaf(acc[j][i][4 * g + 1], sc.y, sh.y);
@@ -447,6 +478,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
         *reinterpret_cast<float4*>(scr + r * PITCH + nl * 4) = v;
       }
     // the scratch is wave-private: LDS operations of one wave complete in order
+    if (i == 0) NBC_STAMP(9);                       // first slab in scratch
 #pragma unroll
     for (int ps2 = 0; ps2 < PASSES; ++ps2) {
       const int pix = ps2 * PIX_PER_PASS + o_pix;
@@ -493,13 +525,22 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_dma_kernel(const ConvArgs
         *reinterpret_cast<uint4*>(yb + eoff) = o;
       }
     }
+    if (i == 0) NBC_STAMP(10);                      // first slab's stores issued
   }
+#ifdef NBC_STAMPS
+  NBC_STAMP(5);                                     // wave 0's stores issued
+  wait_vmcnt<0>();
+  NBC_STAMP(6);                                     // wave 0's stores acknowledged
+  if (p.stamps && threadIdx.x == 0)                 // where the block ran: XCC_ID (reg 20) << 32 | HW_ID (reg 4)
+    p.stamps[(size_t)blockIdx.x * 16 + 7] =
+        ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+#endif
 }
 
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 0>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr int smem = S * (BM + BN) * 128 + 2048;     // ring + scale/shift table
+  constexpr int smem = ring_bytes(PREC, WM, WN, MT, NT, S) + 2048;     // ring (or scratch) + scale/shift table
   static unsigned long long attr_done = 0;     // bit d: attribute set on device d (one context per device)
   auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
   int dev = 0;
@@ -527,6 +568,9 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   6   256x64    4x2            64x32      3       120 KiB  1
 //   7   128x64    2x2            64x32      2       48 KiB   3   (short-K layers: K fits two stages)
 //   8   64x128    1x4            64x32      2       48 KiB   3
+//   9   128x128   4x2            32x64      2       70 KiB   2   (8 waves: short-K layers, where the
+//   10  128x64    4x2            32x32      2       48 KiB   2    serial prologue/epilogue code dominates
+//   11  256x128   4x4            64x32      2       96 KiB   1    and more waves run it in parallel)
 template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
@@ -539,12 +583,15 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, VAR>(a, s);
     case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM, VAR>(a, s);
     case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM, VAR>(a, s);
+    case 9: return launch_cfg<PREC, 4, 2, 1, 2, 2, STEM, VAR>(a, s);
+    case 10: return launch_cfg<PREC, 4, 2, 1, 1, 2, STEM, VAR>(a, s);
+    case 11: return launch_cfg<PREC, 4, 4, 2, 1, 2, STEM, VAR>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128};
 
 }  // namespace
 

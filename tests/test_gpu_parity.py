@@ -250,7 +250,7 @@ def test_errors_are_python_exceptions(gpu_fp32):
         FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
 
 
-@pytest.mark.parametrize("impl,tile", [(0, -1)] + [(1, t) for t in range(9)])
+@pytest.mark.parametrize("impl,tile", [(0, -1)] + [(1, t) for t in range(12)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, impl, tile):
     """Each conv kernel instantiation (register-staged v1; LDS-DMA v2 at every tile shape) against
@@ -285,12 +285,12 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
     try:
         model.set_conv_impl(1, -1)
         base = model(x)
-        for tile in range(9):
+        for tile in range(12):
             model.set_conv_impl(1, tile)
             assert torch.equal(model(x), base), f"tile {tile} changes the logits"
         model.set_conv_impl(1, -1)
         tiles = model.autotune(x, reps=2)
-        assert len(tiles) == 54 and all(0 <= t < 9 for t in tiles)
+        assert len(tiles) == 54 and all(0 <= t < 12 for t in tiles)
         assert torch.equal(model(x), base)
     finally:
         model.set_conv_impl(1, -1)

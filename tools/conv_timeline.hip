@@ -1,0 +1,110 @@
+// Diagnostic: where does a block of the LDS-DMA conv kernel spend its time?
+// Builds conv_igemm_dma.hip with -DNBC_STAMPS (thread 0 of every block stamps the 100 MHz wall clock
+// at phase boundaries) and runs ONE layer shape on random bf16 data.  Not part of the library.
+//   tools/_bin/conv_timeline Hi Wi Ci Co K dil res tile [mfma32]
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "nbc_kernels.hpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static unsigned short rnd_bf16(unsigned& s, float amp) {
+  s = s * 1664525u + 1013904223u;
+  float f = (((s >> 8) & 0xffff) / 65535.0f - 0.5f) * 2.f * amp;
+  unsigned u; __builtin_memcpy(&u, &f, 4);
+  return (unsigned short)(u >> 16);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 9) { std::fprintf(stderr, "usage: %s Hi Wi Ci Co K dil res tile\n", argv[0]); return 2; }
+  const int Hi = atoi(argv[1]), Wi = atoi(argv[2]), Ci = atoi(argv[3]), Co = atoi(argv[4]);
+  const int K = atoi(argv[5]), dil = atoi(argv[6]), res = atoi(argv[7]), tile = atoi(argv[8]);
+  if (Hi < 1 || Wi < 1 || Ci % 64 || Co % 64 || (K != 1 && K != 3) || tile < 0 || tile >= nbc::CONV_TILE_COUNT) return 2;
+  const int M = Hi * Wi, ksteps = K * K * Ci * 2 / 128;
+  const size_t xb = (size_t)M * Ci * 2, wb = (size_t)Co * ksteps * 128, yb = (size_t)M * Co * 2;
+  std::vector<unsigned short> hx(xb / 2), hw(wb / 2), hr(yb / 2);
+  unsigned seed = 12345u;
+  for (auto& v : hx) v = rnd_bf16(seed, 1.f);
+  for (auto& v : hw) v = rnd_bf16(seed, 0.05f);
+  for (auto& v : hr) v = rnd_bf16(seed, 1.f);
+  std::vector<float> hs(Co, 1.0f), hb(Co, 0.01f);
+  void *dx, *dw, *dr, *dy, *dz; float *ds, *db; unsigned long long* dst;
+  CK(hipMalloc(&dx, xb)); CK(hipMalloc(&dw, wb)); CK(hipMalloc(&dr, yb)); CK(hipMalloc(&dy, yb)); CK(hipMalloc(&dz, 256));
+  CK(hipMalloc(&ds, Co * 4)); CK(hipMalloc(&db, Co * 4));
+  CK(hipMemcpy(dx, hx.data(), xb, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), wb, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dr, hr.data(), yb, hipMemcpyHostToDevice)); CK(hipMemset(dz, 0, 256));
+  CK(hipMemcpy(ds, hs.data(), Co * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), Co * 4, hipMemcpyHostToDevice));
+  const int nblk = ((M + nbc::conv_tile_rows(tile) - 1) / nbc::conv_tile_rows(tile)) * (Co / nbc::conv_tile_cols(tile));
+  CK(hipMalloc(&dst, (size_t)nblk * 128)); CK(hipMemset(dst, 0, (size_t)nblk * 128));
+  nbc::ConvArgs a{};
+  a.x = dx; a.w = dw; a.scale = ds; a.shift = db; a.res = res ? dr : nullptr; a.y = dy; a.zero = dz;
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.N = 1; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Hi; a.Wo = Wi; a.Co = Co;
+  a.KH = a.KW = K; a.stride = 1; a.pad = dil * (K / 2); a.dil = dil; a.M = M; a.ksteps = ksteps; a.relu = 1; a.stem = 0;
+  a.wo_shift = -1;
+  for (int s = 0; s < 16; ++s) if ((1 << s) == Wi) a.wo_shift = s;
+  a.stamps = nullptr;
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 20; ++i) CK(nbc::launch_conv_dma(a, 1, tile, st));
+  CK(hipEventRecord(e0, st));
+  const int reps = 50;
+  for (int i = 0; i < reps; ++i) CK(nbc::launch_conv_dma(a, 1, tile, st));
+  CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+  float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps, flops = 2.0 * M * Co * (double)K * K * Ci;
+  a.stamps = dst;
+  CK(nbc::launch_conv_dma(a, 1, tile, st));   // stamped launches: the last one is read
+  CK(nbc::launch_conv_dma(a, 1, tile, st));
+  CK(hipStreamSynchronize(st));
+  std::vector<unsigned long long> h((size_t)nblk * 16);
+  CK(hipMemcpy(h.data(), dst, (size_t)nblk * 128, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 16]); t1 = std::max(t1, h[b * 16 + 6]); }
+  std::printf("shape %dx%d Ci %d Co %d k%d d%d res %d tile %d (%dx%d): %d blocks, %d K-steps | %.1f us/launch back-to-back, %.0f TF | stamped span %.1f us\n",
+              Hi, Wi, Ci, Co, K, dil, res, tile, nbc::conv_tile_rows(tile), nbc::conv_tile_cols(tile), nblk, ksteps, us,
+              flops / us * 1e-6, (t1 - t0) * 0.01);
+  auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+  const char* names[10] = {"start (since first block)", "address set-up done", "prologue issued", "first K-step landed",
+                           "last K-step landed", "MFMAs done", "slab 0 in scratch", "slab 0 stores issued", "stores issued", "stores acked"};
+  const int slot[10] = {0, 8, 1, 2, 3, 4, 9, 10, 5, 6};
+  for (int grp = 0; grp < 2; ++grp) {      // blocks of the first round (start < 1 us) and the later ones
+    size_t cnt = 0;
+    for (int b = 0; b < nblk; ++b) cnt += ((h[b * 16] - t0) * 0.01 < 1.0) == (grp == 0);
+    if (!cnt) continue;
+    std::printf(" %s blocks (%zu):\n", grp == 0 ? "first-round" : "later-round", cnt);
+    for (int i = 0; i < 10; ++i) {
+      std::vector<double> v;
+      for (int b = 0; b < nblk; ++b) {
+        if (((h[b * 16] - t0) * 0.01 < 1.0) != (grp == 0)) continue;
+        unsigned long long s = h[b * 16 + slot[i]];
+        if (slot[i] == 2 && s == 0) s = h[b * 16 + 3];
+        v.push_back(i == 0 ? (s - t0) * 0.01 : (s - h[b * 16]) * 0.01);
+      }
+      std::printf("  %-28s p10 %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us%s\n", names[i], pct(v, 0.1), pct(v, 0.5), pct(v, 0.9),
+                  pct(v, 1.0), i == 0 ? "" : "  (since block start)");
+    }
+  }
+  // residency: blocks per (xcc, se, cu) and how many rounds a CU ran
+  std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> per_cu;
+  for (int b = 0; b < nblk; ++b) {
+    const unsigned long long id = h[b * 16 + 7];
+    const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 0xf;
+    const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
+    per_cu[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back({h[b * 16], h[b * 16 + 6]});
+  }
+  size_t maxb = 0, maxc = 0;
+  for (auto& kv : per_cu) {
+    maxb = std::max(maxb, kv.second.size());
+    size_t conc = 0;
+    for (auto& x : kv.second) { size_t c = 0; for (auto& y : kv.second) if (y.first <= x.first && y.second > x.first) ++c; conc = std::max(conc, c); }
+    maxc = std::max(maxc, conc);
+  }
+  std::printf("  CUs used %zu, blocks per CU max %zu, co-resident per CU max %zu\n", per_cu.size(), maxb, maxc);
+  return 0;
+}
