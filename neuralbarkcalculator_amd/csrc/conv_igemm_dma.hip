@@ -372,24 +372,30 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   // (128 accumulators + 48 fragment registers leave no room: it spilled)
   constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && (VAR == 0 || VAR == 4) && MT * NT >= 8);
   static_assert(WM * WN * 32 * PITCH <= TABLE_OFF, "epilogue scratch must fit below the scale/shift table");
-  unsigned char* yb = static_cast<unsigned char*>(p.y);
-  const unsigned char* resb = static_cast<const unsigned char*>(p.res);
+  // Output addressing: a wave-uniform 64-bit base (first pixel of the tile, first channel of the wave's
+  // slab) plus a 32-bit per-lane offset (row inside the tile x row pitch + the lane's 16-byte chunk).
   const int o_pix = lane / CPR, o_chunk = lane % CPR;
   const int n_slab = n0 + wn * SLAB_CH;
+  const unsigned row_bytes = (unsigned)p.Co * EB;
+  const size_t tile_off = ((size_t)m0 * p.Co + n_slab) * EB;
+  unsigned char* ytile = static_cast<unsigned char*>(p.y) + tile_off;
+  const unsigned char* rtile = p.res ? static_cast<const unsigned char*>(p.res) + tile_off : nullptr;
+  const int rows_valid = p.M - m0;                  // rows of this tile inside the image batch (>= 1)
+  const int row0 = wm * MT * 32 + o_pix;            // + i*32 + pass*PIX_PER_PASS
+  const unsigned lane_chunk = (unsigned)o_chunk * 16u;
   uint4 rpre[RES_PREFETCH ? MT : 1][RES_PREFETCH ? PASSES : 1];
 
   const int T = p.ksteps;
   auto prefetch_identity = [&]() {
     if constexpr (RES_PREFETCH) {
-      if (resb) {
+      if (rtile) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int ps2 = 0; ps2 < PASSES; ++ps2) {
-            int m = m0 + (wm * MT + i) * 32 + ps2 * PIX_PER_PASS + o_pix;
-            m = m < p.M ? m : p.M - 1;                 // tail rows read a valid row; never stored
-            rpre[i][ps2] = *reinterpret_cast<const uint4*>(
-                resb + ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB);
+            int row = row0 + i * 32 + ps2 * PIX_PER_PASS;
+            row = row < rows_valid ? row : rows_valid - 1;   // tail rows read a valid row; never stored
+            rpre[i][ps2] = *reinterpret_cast<const uint4*>(rtile + ((unsigned)row * row_bytes + lane_chunk));
           }
       }
     }
@@ -443,87 +449,114 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   __syncthreads();                                  // every wave has finished reading the ring
   NBC_STAMP(4);                                     // MFMAs done, epilogue starts
   unsigned char* scr = smem + wave * (32 * PITCH);
+  const unsigned char* table = smem + TABLE_OFF + wn * SLAB_CH * 4;
+  const bool relu = p.relu != 0;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    // (a) BN on the accumulators, into the scratch.  The scale/shift reads of a channel group are all
+    // issued before its scratch writes (LDS operations of a wave complete in order, so a table read
+    // behind a scratch write would wait for it).
     if constexpr (M16) {
       // 16x16 D layout: lane (r16, q16) holds pixel r16 and channels 4*q16..4*q16+3 of each tile
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2)
+      for (int j0 = 0; j0 < NT16; j0 += 4) {
+        float4 sc[4], sh[4];
 #pragma unroll
-        for (int j = 0; j < NT16; ++j) {
-          const int nl = j * 16 + 4 * q16;
-          const float4 sc = *reinterpret_cast<const float4*>(smem + TABLE_OFF + (wn * SLAB_CH + nl) * 4);
-          const float4 sh = *reinterpret_cast<const float4*>(smem + TABLE_OFF + 1024 + (wn * SLAB_CH + nl) * 4);
-          const f32x4 a = acc16[j][2 * i + i2];
-          float4 v;
-          v.x = __builtin_fmaf(a[0], sc.x, sh.x);
-          v.y = __builtin_fmaf(a[1], sc.y, sh.y);
-          v.z = __builtin_fmaf(a[2], sc.z, sh.z);
-          v.w = __builtin_fmaf(a[3], sc.w, sh.w);
-          *reinterpret_cast<float4*>(scr + (i2 * 16 + r16) * PITCH + nl * 4) = v;
+        for (int jj = 0; jj < 4 && j0 + jj < NT16; ++jj) {
+          const int nl = (j0 + jj) * 16 + 4 * q16;
+          sc[jj] = *reinterpret_cast<const float4*>(table + nl * 4);
+          sh[jj] = *reinterpret_cast<const float4*>(table + 1024 + nl * 4);
         }
-    } else
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * h;      // channel inside the slab
-        const float4 sc = *reinterpret_cast<const float4*>(smem + TABLE_OFF + (wn * SLAB_CH + nl) * 4);
-        const float4 sh = *reinterpret_cast<const float4*>(smem + TABLE_OFF + 1024 + (wn * SLAB_CH + nl) * 4);
-        float4 v;
-        v.x = __builtin_fmaf(acc[j][i][4 * g + 0], sc.x, sh.x);
-        v.y = __builtin_fmaf(acc[j][i][4 * g + 1], sc.y, sh.y);
-        v.z = __builtin_fmaf(acc[j][i][4 * g + 2], sc.z, sh.z);
-        v.w = __builtin_fmaf(acc[j][i][4 * g + 3], sc.w, sh.w);
-        *reinterpret_cast<float4*>(scr + r * PITCH + nl * 4) = v;
+          for (int jj = 0; jj < 4 && j0 + jj < NT16; ++jj) {
+            const int nl = (j0 + jj) * 16 + 4 * q16;
+            const f32x4 a = acc16[j0 + jj][2 * i + i2];
+            float4 v;
+            v.x = __builtin_fmaf(a[0], sc[jj].x, sh[jj].x);
+            v.y = __builtin_fmaf(a[1], sc[jj].y, sh[jj].y);
+            v.z = __builtin_fmaf(a[2], sc[jj].z, sh[jj].z);
+            v.w = __builtin_fmaf(a[3], sc[jj].w, sh[jj].w);
+            *reinterpret_cast<float4*>(scr + (i2 * 16 + r16) * PITCH + nl * 4) = v;
+          }
       }
-    // the scratch is wave-private: LDS operations of one wave complete in order
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        float4 sc[4], sh[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * h;      // channel inside the slab
+          sc[g] = *reinterpret_cast<const float4*>(table + nl * 4);
+          sh[g] = *reinterpret_cast<const float4*>(table + 1024 + nl * 4);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * h;
+          float4 v;
+          v.x = __builtin_fmaf(acc[j][i][4 * g + 0], sc[g].x, sh[g].x);
+          v.y = __builtin_fmaf(acc[j][i][4 * g + 1], sc[g].y, sh[g].y);
+          v.z = __builtin_fmaf(acc[j][i][4 * g + 2], sc[g].z, sh[g].z);
+          v.w = __builtin_fmaf(acc[j][i][4 * g + 3], sc[g].w, sh[g].w);
+          *reinterpret_cast<float4*>(scr + r * PITCH + nl * 4) = v;
+        }
+      }
+    }
     if (i == 0) NBC_STAMP(9);                       // first slab in scratch
+    // (b) read the slab back row-wise: every lane gets 16 output bytes of one pixel per pass.  All
+    // reads of the slab are issued before the first use (the scratch is wave-private).
+    float v[PASSES][OUT_CH];
 #pragma unroll
     for (int ps2 = 0; ps2 < PASSES; ++ps2) {
-      const int pix = ps2 * PIX_PER_PASS + o_pix;
-      const int m = m0 + (wm * MT + i) * 32 + pix;
-      float v[OUT_CH];
-      const float4* sp = reinterpret_cast<const float4*>(scr + pix * PITCH + o_chunk * OUT_CH * 4);
+      const float4* sp = reinterpret_cast<const float4*>(scr + (ps2 * PIX_PER_PASS + o_pix) * PITCH + o_chunk * OUT_CH * 4);
 #pragma unroll
       for (int q = 0; q < OUT_CH / 4; ++q) {
         const float4 t4 = sp[q];
-        v[4 * q] = t4.x; v[4 * q + 1] = t4.y; v[4 * q + 2] = t4.z; v[4 * q + 3] = t4.w;
+        v[ps2][4 * q] = t4.x; v[ps2][4 * q + 1] = t4.y; v[ps2][4 * q + 2] = t4.z; v[ps2][4 * q + 3] = t4.w;
       }
-      if (m < p.M) {
-        const size_t eoff = ((size_t)m * p.Co + n_slab + o_chunk * OUT_CH) * EB;
-        if (resb) {
-          uint4 rv;
-          if constexpr (RES_PREFETCH) rv = rpre[i][ps2];
-          else rv = *reinterpret_cast<const uint4*>(resb + eoff);
-          if constexpr (PREC == 0) {
-            v[0] += __builtin_bit_cast(float, rv.x); v[1] += __builtin_bit_cast(float, rv.y);
-            v[2] += __builtin_bit_cast(float, rv.z); v[3] += __builtin_bit_cast(float, rv.w);
-          } else {
-            const unsigned u[4] = {rv.x, rv.y, rv.z, rv.w};
+    }
+    // (c) + identity, ReLU (NaN-propagating: v_maximum3_f32), rounding, 16-byte stores in whole row segments
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              v[2 * q] += __builtin_bit_cast(float, u[q] << 16);
-              v[2 * q + 1] += __builtin_bit_cast(float, u[q] & 0xffff0000u);
-            }
+    for (int ps2 = 0; ps2 < PASSES; ++ps2) {
+      const int row = row0 + i * 32 + ps2 * PIX_PER_PASS;
+      const unsigned loff = (unsigned)row * row_bytes + lane_chunk;
+      if (rtile) {
+        uint4 rv;
+        if constexpr (RES_PREFETCH) rv = rpre[i][ps2];
+        else rv = *reinterpret_cast<const uint4*>(rtile + ((unsigned)(row < rows_valid ? row : rows_valid - 1) * row_bytes + lane_chunk));
+        const unsigned u[4] = {rv.x, rv.y, rv.z, rv.w};
+        if constexpr (PREC == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[ps2][q] += __builtin_bit_cast(float, u[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[ps2][2 * q] += __builtin_bit_cast(float, u[q] << 16);
+            v[ps2][2 * q + 1] += __builtin_bit_cast(float, u[q] & 0xffff0000u);
           }
         }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < OUT_CH; ++e) v[e] = v[e] > 0.f ? v[e] : (v[e] != v[e] ? v[e] : 0.f);
-        }
-        uint4 o;
-        if constexpr (PREC == 0) {
-          o.x = __builtin_bit_cast(unsigned, v[0]); o.y = __builtin_bit_cast(unsigned, v[1]);
-          o.z = __builtin_bit_cast(unsigned, v[2]); o.w = __builtin_bit_cast(unsigned, v[3]);
-        } else {
-          o.x = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
-          o.y = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
-          o.z = (unsigned)f32_to_bf16_bits(v[4 % OUT_CH]) | ((unsigned)f32_to_bf16_bits(v[5 % OUT_CH]) << 16);
-          o.w = (unsigned)f32_to_bf16_bits(v[6 % OUT_CH]) | ((unsigned)f32_to_bf16_bits(v[7 % OUT_CH]) << 16);
-        }
-        *reinterpret_cast<uint4*>(yb + eoff) = o;
       }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < OUT_CH; ++e) v[ps2][e] = __builtin_elementwise_maximum(v[ps2][e], 0.f);
+      }
+      uint4 o;
+      if constexpr (PREC == 0) {
+        o.x = __builtin_bit_cast(unsigned, v[ps2][0]); o.y = __builtin_bit_cast(unsigned, v[ps2][1]);
+        o.z = __builtin_bit_cast(unsigned, v[ps2][2]); o.w = __builtin_bit_cast(unsigned, v[ps2][3]);
+      } else {
+        unsigned pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x2 pr = {v[ps2][(2 * q) % OUT_CH], v[ps2][(2 * q + 1) % OUT_CH]};
+          pk[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+        }
+        o.x = pk[0]; o.y = pk[1]; o.z = pk[2]; o.w = pk[3];
+      }
+      if (row < rows_valid) *reinterpret_cast<uint4*>(ytile + loff) = o;
     }
     if (i == 0) NBC_STAMP(10);                      // first slab's stores issued
   }
