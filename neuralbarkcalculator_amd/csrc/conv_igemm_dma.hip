@@ -63,10 +63,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
 #ifdef NBC_STAMPS
 #define NBC_STAMP(i)                                                                                   \
   do {                                                                                                 \
-    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define NBC_STAMP_CLK(i)                                                                               \
+  do {                                                                                                 \
+    if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define NBC_STAMP(i) do { } while (0)
+#define NBC_STAMP_CLK(i) do { } while (0)
 #endif
 
 template <int N>
@@ -415,12 +420,24 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   for (int s = 0; s < S - 1; ++s)
     if (s < T) issue_step(s, s);
   NBC_STAMP(1);                                     // prologue DMAs issued
+#ifdef NBC_STAMPS
+  unsigned long long st_vm = 0, st_bar = 0;         // diagnostic build: cycles each wave spends in the two waits
+#endif
   for (int t = 0; t < T - 1; ++t) {
     // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
+#ifdef NBC_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     if (t + (S - 2) < T) wait_vmcnt<(S - 2) * L>();
     else wait_vmcnt<0>();
+#ifdef NBC_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_s_barrier();
-    if (t == 0) NBC_STAMP(2);                       // first K-step landed
+#ifdef NBC_STAMPS
+    if (t > 0) { st_vm += st1 - st0; st_bar += __builtin_amdgcn_s_memtime() - st1; }
+#endif
+    if (t == 0) { NBC_STAMP(2); NBC_STAMP_CLK(11); }   // first K-step landed
     // the ring slot of step t-1 is free from here on.  With three or more stages its refill (step
     // t+S-1) is issued in four parts, one behind each MFMA cluster of this step; with two stages the
     // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
@@ -436,6 +453,10 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   NBC_STAMP(3);                                     // last K-step landed (main loop done but for its MFMAs)
+  NBC_STAMP_CLK(12);
+#ifdef NBC_STAMPS
+  if (p.stamps && lane == 0) { p.stamps[(size_t)blockIdx.x * 64 + 16 + wave] = st_vm; p.stamps[(size_t)blockIdx.x * 64 + 32 + wave] = st_bar; }
+#endif
   prefetch_identity();
   compute((T - 1) % S, false, 0, 0);
 
@@ -565,7 +586,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   wait_vmcnt<0>();
   NBC_STAMP(6);                                     // wave 0's stores acknowledged
   if (p.stamps && threadIdx.x == 0)                 // where the block ran: XCC_ID (reg 20) << 32 | HW_ID (reg 4)
-    p.stamps[(size_t)blockIdx.x * 16 + 7] =
+    p.stamps[(size_t)blockIdx.x * 64 + 7] =
         ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
 #endif
 }

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dr, hr.data(), yb, hipMemcpyHostToDevice)); CK(hipMemset(dz, 0, 256));
   CK(hipMemcpy(ds, hs.data(), Co * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db, hb.data(), Co * 4, hipMemcpyHostToDevice));
   const int nblk = ((M + nbc::conv_tile_rows(tile) - 1) / nbc::conv_tile_rows(tile)) * (Co / nbc::conv_tile_cols(tile));
-  CK(hipMalloc(&dst, (size_t)nblk * 128)); CK(hipMemset(dst, 0, (size_t)nblk * 128));
+  CK(hipMalloc(&dst, (size_t)nblk * 512)); CK(hipMemset(dst, 0, (size_t)nblk * 512));
   nbc::ConvArgs a{};
   a.x = dx; a.w = dw; a.scale = ds; a.shift = db; a.res = res ? dr : nullptr; a.y = dy; a.zero = dz;
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.N = 1; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Hi; a.Wo = Wi; a.Co = Co;
@@ -58,14 +58,32 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps, flops = 2.0 * M * Co * (double)K * K * Ci;
+  const int nstreams = argc > 9 ? atoi(argv[9]) : 1;
+  if (nstreams > 1) {     // the same launch on several streams at once: do blocks of different launches share CUs?
+    std::vector<hipStream_t> ss(nstreams);
+    std::vector<void*> ys(nstreams);
+    for (int k = 0; k < nstreams; ++k) { CK(hipStreamCreate(&ss[k])); CK(hipMalloc(&ys[k], yb)); }
+    CK(hipDeviceSynchronize());
+    hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+    std::vector<hipEvent_t> done(nstreams);
+    CK(hipEventRecord(f0, st));
+    for (int k = 0; k < nstreams; ++k) CK(hipStreamWaitEvent(ss[k], f0, 0));
+    for (int i = 0; i < reps; ++i)
+      for (int k = 0; k < nstreams; ++k) { nbc::ConvArgs b = a; b.y = ys[k]; CK(nbc::launch_conv_dma(b, 1, tile, ss[k])); }
+    for (int k = 0; k < nstreams; ++k) { CK(hipEventCreate(&done[k])); CK(hipEventRecord(done[k], ss[k])); CK(hipStreamWaitEvent(st, done[k], 0)); }
+    CK(hipEventRecord(f1, st)); CK(hipEventSynchronize(f1));
+    float ms2 = 0; CK(hipEventElapsedTime(&ms2, f0, f1));
+    std::printf("%d streams: %.1f us per launch aggregate (%.0f TF) vs %.1f us alone\n", nstreams, ms2 * 1e3 / (reps * nstreams),
+                flops / (ms2 * 1e3 / (reps * nstreams)) * 1e-6, us);
+  }
   a.stamps = dst;
   CK(nbc::launch_conv_dma(a, 1, tile, st));   // stamped launches: the last one is read
   CK(nbc::launch_conv_dma(a, 1, tile, st));
   CK(hipStreamSynchronize(st));
-  std::vector<unsigned long long> h((size_t)nblk * 16);
-  CK(hipMemcpy(h.data(), dst, (size_t)nblk * 128, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> h((size_t)nblk * 64);
+  CK(hipMemcpy(h.data(), dst, (size_t)nblk * 512, hipMemcpyDeviceToHost));
   unsigned long long t0 = ~0ull, t1 = 0;
-  for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 16]); t1 = std::max(t1, h[b * 16 + 6]); }
+  for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 64]); t1 = std::max(t1, h[b * 64 + 6]); }
   std::printf("shape %dx%d Ci %d Co %d k%d d%d res %d tile %d (%dx%d): %d blocks, %d K-steps | %.1f us/launch back-to-back, %.0f TF | stamped span %.1f us\n",
               Hi, Wi, Ci, Co, K, dil, res, tile, nbc::conv_tile_rows(tile), nbc::conv_tile_cols(tile), nblk, ksteps, us,
               flops / us * 1e-6, (t1 - t0) * 0.01);
@@ -75,28 +93,51 @@ int main(int argc, char** argv) {
   const int slot[10] = {0, 8, 1, 2, 3, 4, 9, 10, 5, 6};
   for (int grp = 0; grp < 2; ++grp) {      // blocks of the first round (start < 1 us) and the later ones
     size_t cnt = 0;
-    for (int b = 0; b < nblk; ++b) cnt += ((h[b * 16] - t0) * 0.01 < 1.0) == (grp == 0);
+    for (int b = 0; b < nblk; ++b) cnt += ((h[b * 64] - t0) * 0.01 < 1.0) == (grp == 0);
     if (!cnt) continue;
     std::printf(" %s blocks (%zu):\n", grp == 0 ? "first-round" : "later-round", cnt);
     for (int i = 0; i < 10; ++i) {
       std::vector<double> v;
       for (int b = 0; b < nblk; ++b) {
-        if (((h[b * 16] - t0) * 0.01 < 1.0) != (grp == 0)) continue;
-        unsigned long long s = h[b * 16 + slot[i]];
-        if (slot[i] == 2 && s == 0) s = h[b * 16 + 3];
-        v.push_back(i == 0 ? (s - t0) * 0.01 : (s - h[b * 16]) * 0.01);
+        if (((h[b * 64] - t0) * 0.01 < 1.0) != (grp == 0)) continue;
+        unsigned long long s = h[b * 64 + slot[i]];
+        if (slot[i] == 2 && s == 0) s = h[b * 64 + 3];
+        v.push_back(i == 0 ? (s - t0) * 0.01 : (s - h[b * 64]) * 0.01);
       }
       std::printf("  %-28s p10 %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us%s\n", names[i], pct(v, 0.1), pct(v, 0.5), pct(v, 0.9),
                   pct(v, 1.0), i == 0 ? "" : "  (since block start)");
     }
   }
+  {  // shader clock held inside the K loop: core cycles (s_memtime) per 100 MHz wall tick
+    std::vector<double> ghz, util, fvm, fbar;
+    double wvm[16] = {0}, wbar[16] = {0}; int wn = 0;
+    const double mfma_cyc_per_step = (double)nbc::conv_tile_rows(tile) * nbc::conv_tile_cols(tile) * 64.0 / (4 * 512.0);   // 512 MAC/clk/SIMD (bf16)
+    for (int b = 0; b < nblk; ++b) {
+      const double dt = (double)(h[b * 64 + 3] - h[b * 64 + 2]), dc = (double)(h[b * 64 + 12] - h[b * 64 + 11]);
+      if (h[b * 64 + 2] == 0 || dt < 50) continue;
+      ghz.push_back(dc / dt * 0.1);
+      util.push_back(mfma_cyc_per_step * (ksteps - 1) / dc);
+      fvm.push_back((double)h[b * 64 + 16] / dc);
+      fbar.push_back((double)h[b * 64 + 32] / dc);
+      for (int w = 0; w < 16; ++w) { wvm[w] += (double)h[b * 64 + 16 + w] / dc; wbar[w] += (double)h[b * 64 + 32 + w] / dc; }
+      ++wn;
+    }
+    if (!ghz.empty())
+      std::printf("  K loop: shader clock p50 %.2f GHz (p10 %.2f, p90 %.2f); MFMA-busy share of its cycles p50 %.2f; wave 0 waits: vmcnt %.2f, barrier %.2f of the loop\n",
+                  pct(ghz, 0.5), pct(ghz, 0.1), pct(ghz, 0.9), pct(util, 0.5), pct(fvm, 0.5), pct(fbar, 0.5));
+    if (wn) {
+      std::printf("  per wave, mean share of the loop in vmcnt wait | barrier wait:");
+      for (int w = 0; w < 16; ++w) if (wvm[w] + wbar[w] > 0) std::printf("  w%d %.2f|%.2f", w, wvm[w] / wn, wbar[w] / wn);
+      std::printf("\n");
+    }
+  }
   // residency: blocks per (xcc, se, cu) and how many rounds a CU ran
   std::map<unsigned long long, std::vector<std::pair<unsigned long long, unsigned long long>>> per_cu;
   for (int b = 0; b < nblk; ++b) {
-    const unsigned long long id = h[b * 16 + 7];
+    const unsigned long long id = h[b * 64 + 7];
     const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 0xf;
     const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
-    per_cu[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back({h[b * 16], h[b * 16 + 6]});
+    per_cu[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back({h[b * 64], h[b * 64 + 6]});
   }
   size_t maxb = 0, maxc = 0;
   for (auto& kv : per_cu) {
