@@ -426,11 +426,12 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         const PackedConv& pc = c->layout.convs[o.unit];
         if (o.Ci != 512) return set_error(NBC_ERR_STATE, "classifier.4 expects 512 input channels");
         e = launch_head1x1(c->bufs[o.in_buf], reinterpret_cast<const float*>(c->weights + pc.w_off),
-                           reinterpret_cast<const float*>(c->weights + pc.shift_off), lowres, N, o.Ho * o.Wo, prec, s);
+                           reinterpret_cast<const float*>(c->weights + pc.shift_off), lowres, N, o.Ho * o.Wo, prec,
+                           reinterpret_cast<unsigned long long*>(counts_dev), s);   // also clears the counters
         break;
       }
       case OP_UPSAMPLE:
-        if (counts_dev) {
+        if (counts_dev && 3 * N > 256) {             // more counters than classifier.4's launch clears
           e = hipMemsetAsync(counts_dev, 0, sizeof(int64_t) * 3 * N, s);
           if (e != hipSuccess) break;
         }

@@ -1,6 +1,8 @@
 // Memory-bound kernels of the path: image ingest, max-pool, the 1x1 classifier and the fused
 // bicubic-upsample + argmax + class-count kernel.  All are HBM/L2-bound byte movers: 16-byte
 // lane accesses, no MFMA.
+#include <cstdlib>
+
 #include "nbc_kernels.hpp"
 
 namespace nbc {
@@ -55,67 +57,63 @@ __global__ void ingest_u8_kernel(const uint8_t* __restrict__ x, void* __restrict
   }
 }
 
-// MaxPool2d(kernel 3, stride 2, padding 1): padding is -inf, i.e. out-of-range taps are skipped;
-// NaN propagates like ATen's max_pool2d (a NaN tap wins).
+// MaxPool2d(kernel 3, stride 2, padding 1): padding is -inf, i.e. out-of-range taps do not count;
+// NaN propagates like ATen's max_pool2d (a NaN tap wins): v_maximum3_f32.
+// grid = (ceil(Wo*chunks / 256), Ho, N); a thread owns one 16-byte channel chunk of one output pixel,
+// consecutive threads consecutive chunks (whole 128/256-byte pixel rows per 8/16 lanes).
 template <int PREC>
-__global__ void maxpool_kernel(const void* __restrict__ x, void* __restrict__ y, int N, int Hi, int Wi,
-                               int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void maxpool_kernel(const void* __restrict__ x, void* __restrict__ y, int Hi, int Wi,
+                                                      int chunk_shift, int Ho, int Wo) {
   constexpr int EPC = PREC == 0 ? 4 : 8;          // elements per 16-byte chunk
-  const int chunks = C / EPC;
-  const size_t total = (size_t)N * Ho * Wo * chunks;
-  const uint4* xv = static_cast<const uint4*>(x);
-  uint4* yv = static_cast<uint4*>(y);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(i % chunks);
-    size_t pix = i / chunks;
-    const int ox = (int)(pix % Wo);
-    pix /= Wo;
-    const int oy = (int)(pix % Ho);
-    const int img = (int)(pix / Ho);
-    float best[EPC];
+  const int chunks = 1 << chunk_shift;
+  const int e = blockIdx.x * 256 + threadIdx.x;   // (ox, chunk)
+  const int ox = e >> chunk_shift, ch = e & (chunks - 1);
+  const int oy = blockIdx.y, img = blockIdx.z;
+  if (ox >= Wo) return;
+  const uint4* xv = static_cast<const uint4*>(x) + (size_t)img * Hi * Wi * chunks + ch;
+  float best[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) best[e] = -__builtin_inff();
+  for (int k = 0; k < EPC; ++k) best[k] = -__builtin_inff();
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int iy = oy * 2 - 1 + dy;
-      if ((unsigned)iy >= (unsigned)Hi) continue;
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = oy * 2 - 1 + dy;
+    const bool oky = (unsigned)iy < (unsigned)Hi;
+    const int cy = oky ? iy : oy * 2;             // a valid row to read when the tap is padding
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int ix = ox * 2 - 1 + dx;
-        if ((unsigned)ix >= (unsigned)Wi) continue;
-        const uint4 v = xv[((size_t)(img * Hi + iy) * Wi + ix) * chunks + ch];
-        float f[EPC];
-        if constexpr (PREC == 0) {
-          f[0] = __builtin_bit_cast(float, v.x); f[1] = __builtin_bit_cast(float, v.y);
-          f[2] = __builtin_bit_cast(float, v.z); f[3] = __builtin_bit_cast(float, v.w);
-        } else {
-          const unsigned u[4] = {v.x, v.y, v.z, v.w};
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ox * 2 - 1 + dx;
+      const bool ok = oky && (unsigned)ix < (unsigned)Wi;
+      const int cx = (unsigned)ix < (unsigned)Wi ? ix : ox * 2;
+      const uint4 v = xv[((size_t)cy * Wi + cx) * chunks];
+      float f[EPC];
+      if constexpr (PREC == 0) {
+        f[0] = __builtin_bit_cast(float, v.x); f[1] = __builtin_bit_cast(float, v.y);
+        f[2] = __builtin_bit_cast(float, v.z); f[3] = __builtin_bit_cast(float, v.w);
+      } else {
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f[2 * q] = __builtin_bit_cast(float, u[q] << 16);
-            f[2 * q + 1] = __builtin_bit_cast(float, u[q] & 0xffff0000u);
-          }
+        for (int q = 0; q < 4; ++q) {
+          f[2 * q] = __builtin_bit_cast(float, u[q] << 16);
+          f[2 * q + 1] = __builtin_bit_cast(float, u[q] & 0xffff0000u);
         }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          if (f[e] > best[e] || f[e] != f[e]) best[e] = f[e];
       }
-    }
-    uint4 o;
-    if constexpr (PREC == 0) {
-      o.x = __builtin_bit_cast(unsigned, best[0]); o.y = __builtin_bit_cast(unsigned, best[1]);
-      o.z = __builtin_bit_cast(unsigned, best[2]); o.w = __builtin_bit_cast(unsigned, best[3]);
-    } else {          // inputs were bf16, so the max is exactly representable: truncate
-      unsigned u[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        u[q] = (__builtin_bit_cast(unsigned, best[2 * q]) >> 16) |
-               (__builtin_bit_cast(unsigned, best[2 * q + 1]) & 0xffff0000u);
-      o = make_uint4(u[0], u[1], u[2], u[3]);
+      for (int k = 0; k < EPC; ++k) best[k] = __builtin_elementwise_maximum(best[k], ok ? f[k] : -__builtin_inff());
     }
-    yv[i] = o;
   }
+  uint4 o;
+  if constexpr (PREC == 0) {
+    o.x = __builtin_bit_cast(unsigned, best[0]); o.y = __builtin_bit_cast(unsigned, best[1]);
+    o.z = __builtin_bit_cast(unsigned, best[2]); o.w = __builtin_bit_cast(unsigned, best[3]);
+  } else {          // inputs were bf16, so the max is exactly representable: truncate
+    unsigned u[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      u[q] = (__builtin_bit_cast(unsigned, best[2 * q]) >> 16) |
+             (__builtin_bit_cast(unsigned, best[2 * q + 1]) & 0xffff0000u);
+    o = make_uint4(u[0], u[1], u[2], u[3]);
+  }
+  static_cast<uint4*>(y)[(((size_t)img * Ho + oy) * Wo + ox) * chunks + ch] = o;
 }
 
 // classifier.4 (models.py:121): 1x1 conv 512 -> 3 with bias.  One wave per pixel: lane l owns
@@ -124,7 +122,8 @@ template <int PREC>
 __global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ bias,
-                                                      float* __restrict__ y, int M, int hw) {
+                                                      float* __restrict__ y, int M, int hw,
+                                                      unsigned long long* __restrict__ counts_zero, int ncounts) {
   constexpr int CIN = 512;
   constexpr int PIX_PER_WAVE = 8;
   const int lane = threadIdx.x & 63;
@@ -136,17 +135,30 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x
     for (int e = 0; e < 8; ++e) wr[c][e] = w[c * CIN + lane * 8 + e];
   const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
   const int first = (blockIdx.x * 4 + wave) * PIX_PER_WAVE;
+  if (counts_zero && blockIdx.x == 0 && threadIdx.x < ncounts) counts_zero[threadIdx.x] = 0ull;   // for the next launch
+  // the wave's 8 pixel rows are requested together (one memory round trip), then reduced one by one
+  constexpr int VPP = PREC == 0 ? 2 : 1;                  // 16-byte loads per lane and pixel
+  uint4 raw[PIX_PER_WAVE][VPP];
+#pragma unroll
+  for (int q = 0; q < PIX_PER_WAVE; ++q) {
+    const int m = min(first + q, M - 1);
+    const uint4* xp = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(x) +
+                                                     ((size_t)m * CIN + lane * 8) * (PREC == 0 ? 4 : 2));
+#pragma unroll
+    for (int k = 0; k < VPP; ++k) raw[q][k] = xp[k];
+  }
+#pragma unroll
   for (int q = 0; q < PIX_PER_WAVE; ++q) {
     const int m = first + q;
-    if (m >= M) break;                                   // wave-uniform
     float f[8];
     if constexpr (PREC == 0) {
-      const float4* xp = reinterpret_cast<const float4*>(static_cast<const float*>(x) + (size_t)m * CIN + lane * 8);
-      const float4 a = xp[0], b = xp[1];
-      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+      const uint4 a = raw[q][0], b = raw[q][VPP - 1];
+      f[0] = __builtin_bit_cast(float, a.x); f[1] = __builtin_bit_cast(float, a.y);
+      f[2] = __builtin_bit_cast(float, a.z); f[3] = __builtin_bit_cast(float, a.w);
+      f[4] = __builtin_bit_cast(float, b.x); f[5] = __builtin_bit_cast(float, b.y);
+      f[6] = __builtin_bit_cast(float, b.z); f[7] = __builtin_bit_cast(float, b.w);
     } else {
-      const uint4 v = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(x) + (size_t)m * CIN + lane * 8);
-      const unsigned u[4] = {v.x, v.y, v.z, v.w};
+      const unsigned u[4] = {raw[q][0].x, raw[q][0].y, raw[q][0].z, raw[q][0].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         f[2 * k] = __builtin_bit_cast(float, u[k] << 16);
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x
     for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
       for (int c = 0; c < 3; ++c) s[c] += __shfl_xor(s[c], off, 64);
-    if (lane == 0) {
+    if (lane == 0 && m < M) {
       const int img = m / hw, pix = m - img * hw;
       float* yp = y + (size_t)img * 3 * hw + pix;
       yp[0] = s[0] + b0;
@@ -271,8 +283,9 @@ __global__ __launch_bounds__(256) void upsample_argmax_kernel(
 // class, edge-clamped) into LDS, so the 48 taps per pixel are LDS reads instead of 48 gather loads
 // (the one-pixel-per-thread kernel above was texture-address bound: 62 us per 1024^2 image).
 // Arithmetic and its order are identical to upsample_argmax_kernel.
-constexpr int UP_ROWS = 8, UP_WIN_R = 8, UP_WIN_C = 72;
+constexpr int UP_WIN_R = 9, UP_WIN_C = 72;
 
+template <int UP_ROWS>
 __global__ __launch_bounds__(256) void upsample_argmax_tiled_kernel(
     const float* __restrict__ lowres, int h, int w, int H, int W, float scale_y, float scale_x,
     float* __restrict__ logits_full, void* __restrict__ labels, int labels_i64,
@@ -288,12 +301,23 @@ __global__ __launch_bounds__(256) void upsample_argmax_tiled_kernel(
   const int wy0 = ti[0];                       // tap indices are monotone in the output index
   cubic_setup(ox0, scale_x, w, ti, tc);
   const int wx0 = ti[0];
-  for (int e = tid; e < 3 * UP_WIN_R * UP_WIN_C; e += 256) {
+  // all of a thread's window loads are issued before the first LDS store (one memory round trip
+  // per block instead of one per loop iteration)
+  constexpr int WIN_ELEMS = 3 * UP_WIN_R * UP_WIN_C, WIN_ITERS = (WIN_ELEMS + 255) / 256;
+  float wv[WIN_ITERS];
+#pragma unroll
+  for (int it = 0; it < WIN_ITERS; ++it) {
+    const int e = min(tid + it * 256, WIN_ELEMS - 1);
     const int c = e / (UP_WIN_R * UP_WIN_C);
     const int rem = e - c * (UP_WIN_R * UP_WIN_C);
     const int rr = rem / UP_WIN_C, cc = rem - rr * UP_WIN_C;
     const int sy = min(wy0 + rr, h - 1), sx = min(wx0 + cc, w - 1);
-    win[c][rr][cc] = lowres[(((size_t)img * 3 + c) * h + sy) * w + sx];
+    wv[it] = lowres[(((size_t)img * 3 + c) * h + sy) * w + sx];
+  }
+#pragma unroll
+  for (int it = 0; it < WIN_ITERS; ++it) {
+    const int e = tid + it * 256;
+    if (e < WIN_ELEMS) (&win[0][0][0])[e] = wv[it];
   }
   __syncthreads();
   const int ox = ox0 + tid;
@@ -409,19 +433,23 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int N, int Hi, int Wi, in
                                int precision, hipStream_t s) {
   const int epc = precision == 0 ? 4 : 8;
   if (C % epc != 0) return hipErrorInvalidValue;
-  const size_t total = (size_t)N * Ho * Wo * (C / epc);
-  const int g = grid_for(total, 256);
-  if (precision == 0) hipLaunchKernelGGL(maxpool_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, Hi, Wi, C, Ho, Wo);
-  else hipLaunchKernelGGL(maxpool_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, Hi, Wi, C, Ho, Wo);
+  const int chunks = C / epc;
+  int shift = 0;
+  while ((1 << shift) < chunks) ++shift;
+  if ((1 << shift) != chunks || chunks > 256 || Ho > 65535 || N > 65535) return hipErrorInvalidValue;   // C = 64 on this path
+  dim3 grid((Wo * chunks + 255) / 256, Ho, N);
+  if (precision == 0) hipLaunchKernelGGL(maxpool_kernel<0>, grid, dim3(256), 0, s, x, y, Hi, Wi, shift, Ho, Wo);
+  else hipLaunchKernelGGL(maxpool_kernel<1>, grid, dim3(256), 0, s, x, y, Hi, Wi, shift, Ho, Wo);
   return hipGetLastError();
 }
 
 hipError_t launch_head1x1(const void* x, const float* w, const float* bias, float* y, int N, int hw,
-                          int precision, hipStream_t s) {
+                          int precision, unsigned long long* counts_zero, hipStream_t s) {
+  if (3 * N > 256) counts_zero = nullptr;      // the caller then clears the counters itself
   const int M = N * hw;
   const int blocks = (M + 31) / 32;           // 4 waves x 8 pixels
-  if (precision == 0) hipLaunchKernelGGL(head1x1_kernel<0>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw);
-  else hipLaunchKernelGGL(head1x1_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw);
+  if (precision == 0) hipLaunchKernelGGL(head1x1_kernel<0>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
+  else hipLaunchKernelGGL(head1x1_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
   return hipGetLastError();
 }
 
@@ -434,10 +462,12 @@ hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int 
   const float scale_x = (float)w / (float)W;
   // the tiled kernel needs the block's tap window to fit its LDS image (always true for the
   // path's own x8 geometry: 36 x 5 taps); anything else takes the one-pixel-per-thread kernel
-  const bool fits = (int)(scale_x * 255.0f) + 6 <= UP_WIN_C && (int)(scale_y * (UP_ROWS - 1)) + 6 <= UP_WIN_R;
+  static const int up_rows = [] { const char* e = getenv("NBC_UP_ROWS"); const int v = e ? atoi(e) : 8; return v == 16 || v == 4 ? v : 8; }();
+  const bool fits = (int)(scale_x * 255.0f) + 6 <= UP_WIN_C && (int)(scale_y * (up_rows - 1)) + 6 <= UP_WIN_R;
   if (fits) {
-    dim3 grid((W + 255) / 256, (H + UP_ROWS - 1) / UP_ROWS, N);
-    hipLaunchKernelGGL(upsample_argmax_tiled_kernel, grid, dim3(256), 0, s, lowres, h, w, H, W, scale_y,
+    dim3 grid((W + 255) / 256, (H + up_rows - 1) / up_rows, N);
+    auto kern = up_rows == 16 ? &upsample_argmax_tiled_kernel<16> : up_rows == 4 ? &upsample_argmax_tiled_kernel<4> : &upsample_argmax_tiled_kernel<8>;
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, lowres, h, w, H, W, scale_y,
                        scale_x, logits_full, labels, labels_i64, counts, exclude_nodes);
   } else {
     dim3 grid((W + 255) / 256, H, N);
