@@ -233,7 +233,7 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     for k, gi in enumerate(mine):
         path, name, wood = images[gi]
         with open(path, "rb") as f:
-            img = np.ascontiguousarray(np.asarray(Image.open(f).convert("RGB")))
+            img = np.array(Image.open(f).convert("RGB"))          # own, writable, contiguous copy
         x = torch.from_numpy(img)[None].to(dev)                      # uint8 NHWC; normalised on device
         labels, counts = model.predict_labels(x, exclude_nodes=False, labels_dtype=torch.uint8)
         lab = labels[0].cpu().numpy()

@@ -294,3 +294,61 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
         assert torch.equal(model(x), base)
     finally:
         model.set_conv_impl(1, -1)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_nan_propagates_like_the_oracle(oracle_model, gpu_fp32, gpu_bf16, mode):
+    """A NaN input pixel poisons exactly the activations the oracle says it poisons, layer by layer:
+    NaN goes through every conv tap that touches it, through BN, through ReLU (torch.relu keeps NaN),
+    through max-pooling (a NaN tap wins) and the residual adds; everything else stays finite and
+    within the usual tolerance.  (At the logits the receptive field covers the whole 128x128 image.)"""
+    from oracle.fcn_resnet50_oracle import layer_outputs
+    model = gpu_fp32 if mode == "fp32" else gpu_bf16
+    rtol = LAYER_RTOL_FP32 if mode == "fp32" else LAYER_RTOL_BF16
+    x = frames([21], 128, 128)
+    x[0, 1, 40, 70] = float("nan")
+    ref = layer_outputs(oracle_model, x)
+    model.set_keep_activations(True)
+    try:
+        labels, counts, lowres = model.predict_labels(x.to(DEV), return_lowres=True)
+        torch.cuda.synchronize()
+        partial = 0
+        for name, want_t in ref.items():
+            want = want_t.numpy()
+            got = lowres.cpu().numpy() if name == "classifier.4" else model.read_activation(name, want.size)
+            got = got.reshape(want.shape)
+            nan_ref, nan_got = np.isnan(want), np.isnan(got)
+            assert np.array_equal(nan_ref, nan_got), f"{name}: NaN masks differ on {int((nan_ref != nan_got).sum())} values ({mode})"
+            partial += int(nan_ref.any() and not nan_ref.all())
+            fin = ~nan_ref
+            if fin.any():
+                scale = float(np.abs(want[fin]).max())
+                err = float(np.abs(got[fin] - want[fin]).max())
+                assert err <= rtol * max(scale, 1e-6), f"{name}: finite part off by {err} vs scale {scale} ({mode})"
+        assert partial >= 10, "the probe must leave partly finite activations in the early layers"
+    finally:
+        model.set_keep_activations(False)
+    labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
+    assert torch.equal(torch.isnan(lowres_ref), torch.isnan(lowres.cpu()))
+    nan_px = torch.isnan(logits_ref).any(dim=1)
+    assert torch.equal(labels.cpu()[nan_px], labels_ref[nan_px])     # argmax: the first NaN class wins
+    assert int(counts.sum()) == labels.numel()
+
+
+@pytest.mark.parametrize("shape", [(1, 9, 9), (1, 31, 45), (3, 40, 72), (1, 200, 1000), (2, 129, 65)])
+def test_ragged_shapes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, shape):
+    """Heights/widths that are not multiples of the stride-8 grid, of a tile, or of anything: partial
+    tiles in every conv, clamped bicubic taps, the generic (non-power-of-two width) row decode and the
+    one-pixel-per-thread upsample kernel (windows that do not fit the tiled kernel's LDS image)."""
+    n, h, w = shape
+    x = frames(range(30, 30 + n), h, w)
+    labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
+    scale = float(lowres_ref.abs().max())
+    for model, rtol, min_agree in ((gpu_fp32, LOGIT_RTOL_FP32, 0.9995), (gpu_bf16, LOGIT_RTOL_BF16, 0.97)):
+        labels, counts, lowres = model.predict_labels(x.to(DEV), return_lowres=True)
+        assert tuple(labels.shape) == (n, h, w) and tuple(lowres.shape) == tuple(lowres_ref.shape)
+        err = float((lowres.cpu() - lowres_ref).abs().max())
+        assert err <= rtol * scale, f"{shape}: low-res logit error {err} vs scale {scale}"
+        agree = float((labels.cpu() == labels_ref).float().mean())
+        assert agree >= min_agree, f"{shape}: label agreement {agree}"
+        assert torch.equal(counts.cpu().sum(dim=1), torch.full((n,), h * w, dtype=torch.int64))
