@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the short fp32 parity-mode leg that is reported next to a bf16 run")
+    ap.add_argument("--keep-tiles", action="store_true",
+                    help="instrumented single-stream region keeps the tiles tuned for the overlapped region")
     ap.add_argument("--no-op-events", action="store_true", help="timed region without per-launch HIP events")
     return ap.parse_args()
 
@@ -193,7 +195,7 @@ def main():
     # wall time is reported as roofline.instrumented_ms_per_step.
     records, dt_events, dt_single = [], None, None
     if not args.no_op_events:
-        if tiles is not None and nstreams > 1:
+        if tiles is not None and nstreams > 1 and not args.keep_tiles:
             model.autotune(batches[0], objective="latency")
         for i in range(min(args.warmup, 3)):
             step(i, 0)
