@@ -177,6 +177,11 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   const unsigned wave_off = (unsigned)wave * 1024u;
   const int cblocks = STEM ? 1 : pix_bytes / 128;                 // K-steps per tap
   int ld_kh = 0, ld_kw = 0, ld_cb = 0;
+  int st_kh = 0, st_kw = 0;                                       // stem only: the lane's tap, see issue_one
+  if constexpr (STEM) {
+    st_kw = a_coff[0] >> 4;
+    while (st_kw >= p.KW) { st_kw -= p.KW; ++st_kh; }
+  }
 
   // Source pointers of the activation rows for the CURRENT tap.  Inside a tap a K-step only moves
   // 128 bytes along the channels, so the per-step work is one pointer add per row; the bounds test
@@ -205,10 +210,11 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
         dma16(a_ptr[i], sa + (unsigned)(ROWS_PER_PASS * 128 * i));
         a_ptr[i] += a_inc[i];
       } else {
-        const int tap = t * 8 + (a_coff[i] >> 4);      // stem: one chunk = one tap's padded pixel
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const int iy = a_iy0[i] + kh * p.dil, ix = a_ix0[i] + kw * p.dil;
-        const bool ok = tap < p.KH * p.KW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        // stem: one chunk = one tap's padded pixel; this lane's tap of the K-step being issued is
+        // (st_kh, st_kw), advanced by 8 taps per K-step without a division (all passes of a lane
+        // share the chunk: ROWS_PER_PASS is a multiple of 16)
+        const int iy = a_iy0[i] + st_kh * p.dil, ix = a_ix0[i] + st_kw * p.dil;
+        const bool ok = st_kh < p.KH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * 16;
         const unsigned char* src = ok ? xb + off : zpage;
         dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
@@ -227,6 +233,12 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
 #pragma unroll
     for (int d = 0; d < L; ++d)
       if (d * 4 / L == part) issue_one(d, t, sa);
+    if constexpr (STEM) {
+      if (part == 3) {                             // next K-step: eight taps further
+        st_kw += 8;
+        while (st_kw >= p.KW) { st_kw -= p.KW; ++st_kh; }
+      }
+    }
     if constexpr (!STEM) {
       if (part == 3) {
         if (++ld_cb == cblocks) {                  // wave-uniform: next K-step starts a new tap

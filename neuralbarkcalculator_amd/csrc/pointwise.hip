@@ -32,14 +32,19 @@ __device__ __forceinline__ void store_pixel(void* y, size_t pix, float c0, float
 
 // `batch[0].to(device)` of models.py:269: float32 NCHW in, NHWC out.
 template <int PREC>
-__global__ void ingest_f32_kernel(const float* __restrict__ x, void* __restrict__ y, int N, int HW) {
-  const size_t total = (size_t)N * HW;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const size_t img = i / HW, pix = i - img * HW;
-    const float* xp = x + img * 3 * (size_t)HW + pix;
-    store_pixel<PREC>(y, i, xp[0], xp[(size_t)HW], xp[2 * (size_t)HW]);
+__global__ __launch_bounds__(256) void ingest_f32_kernel(const float* __restrict__ x, void* __restrict__ y, int HW) {
+  // grid = (ceil(HW / 512), N): two pixels per thread, no index division
+  const int img = blockIdx.y;
+  const float* xp = x + (size_t)img * 3 * HW;
+  const int p0 = blockIdx.x * 512 + threadIdx.x, p1 = p0 + 256;
+  float a[3], b[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    a[c] = p0 < HW ? xp[(size_t)c * HW + p0] : 0.f;
+    b[c] = p1 < HW ? xp[(size_t)c * HW + p1] : 0.f;
   }
+  if (p0 < HW) store_pixel<PREC>(y, (size_t)img * HW + p0, a[0], a[1], a[2]);
+  if (p1 < HW) store_pixel<PREC>(y, (size_t)img * HW + p1, b[0], b[1], b[2]);
 }
 
 // ToTensor (u8 / 255) then Normalize ((x - mean) / std), dataset.py:175-186, in IEEE f32.
@@ -409,10 +414,11 @@ inline int grid_for(size_t total, int block) {
 }  // namespace
 
 hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int precision, hipStream_t s) {
-  const size_t total = (size_t)N * H * W;
-  const int g = grid_for(total, 256);
-  if (precision == 0) hipLaunchKernelGGL(ingest_f32_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, H * W);
-  else hipLaunchKernelGGL(ingest_f32_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, H * W);
+  if (N > 65535 || (long long)H * W > 0x7fffffffLL) return hipErrorInvalidValue;
+  const int HW = H * W;
+  dim3 grid((HW + 511) / 512, N);
+  if (precision == 0) hipLaunchKernelGGL(ingest_f32_kernel<0>, grid, dim3(256), 0, s, x, y, HW);
+  else hipLaunchKernelGGL(ingest_f32_kernel<1>, grid, dim3(256), 0, s, x, y, HW);
   return hipGetLastError();
 }
 
