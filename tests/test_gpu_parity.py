@@ -352,3 +352,32 @@ def test_ragged_shapes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, shape):
         agree = float((labels.cpu() == labels_ref).float().mean())
         assert agree >= min_agree, f"{shape}: label agreement {agree}"
         assert torch.equal(counts.cpu().sum(dim=1), torch.full((n,), h * w, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_overlapped_forwards_on_four_streams(gpu_fp32, gpu_bf16, mode):
+    """bench.py's default: four model objects sharing one packed weight blob (`clone_shared`), each
+    with its own workspace, running different frames at the same time on four HIP streams with
+    throughput-tuned tiles.  Every result must equal the one the same frame gives alone."""
+    model = gpu_fp32 if mode == "fp32" else gpu_bf16
+    dev = torch.device(DEV)
+    xs = [frames([40 + k], 256, 256).to(dev) for k in range(4)]
+    alone = [model.predict_labels(x, return_lowres=True) for x in xs]
+    torch.cuda.synchronize()
+    models = [model] + [model.clone_shared() for _ in range(3)]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(3)]
+    try:
+        for m in models:
+            m.autotune(xs[0], objective="throughput")
+        torch.cuda.synchronize()
+        outs = [None] * 4
+        for rep in range(3):                      # several rounds so that launches really interleave
+            for k in range(4):
+                with torch.cuda.stream(streams[k]):
+                    outs[k] = models[k].predict_labels(xs[k], return_lowres=True)
+        torch.cuda.synchronize()
+        for k in range(4):
+            for got, want in zip(outs[k], alone[k]):
+                assert torch.equal(got, want), f"stream {k} differs from the same frame alone ({mode})"
+    finally:
+        model.autotune(xs[0], objective="latency")
