@@ -230,13 +230,20 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     images = list_images(os.path.join(root, "processed"))
     mine = shard_indices(len(images), rank, world)
     rows = np.zeros((len(mine), ROW_WIDTH), dtype=np.int64)
-    for k, gi in enumerate(mine):
-        path, name, wood = images[gi]
-        with open(path, "rb") as f:
-            img = np.array(Image.open(f).convert("RGB"))          # own, writable, contiguous copy
-        x = torch.from_numpy(img)[None].to(dev)                      # uint8 NHWC; normalised on device
-        labels, counts = model.predict_labels(x, exclude_nodes=False, labels_dtype=torch.uint8)
-        lab = labels[0].cpu().numpy()
+
+    # The forward is ~1.4 ms per image; decoding the PNG, removing small zones and writing the label
+    # PNG are tens of milliseconds of host work each.  They run on a small thread pool around the GPU
+    # loop (PIL, numpy and scipy release the GIL in their C code): a few images are decoded ahead and
+    # every image's post-processing is handed off as soon as its labels are on the host.
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    def load(gi):
+        with open(images[gi][0], "rb") as f:
+            return np.array(Image.open(f).convert("RGB"))           # own, writable, contiguous copy
+
+    def finish(gi, lab, counts):
+        _, name, wood = images[gi]
         if small_zones:                                              # models.py:271
             lab = remove_small_zones(lab)
         if exclude_nodes:                                            # models.py:273-276
@@ -244,9 +251,26 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         if small_zones or exclude_nodes:
             c1, c2 = int((lab == 1).sum()), int((lab == 2).sum())
         else:
-            c1, c2 = int(counts[0, 1]), int(counts[0, 2])
-        rows[k] = (gi, lab.shape[0], lab.shape[1], c1, c2)
+            c1, c2 = counts
         Image.fromarray(label_png(lab), mode="L").save(os.path.join(root, "results", "outputs", wood, name))
+        return (gi, lab.shape[0], lab.shape[1], c1, c2)
+
+    workers = max(1, min(8, int(os.environ.get("NBC_HOST_WORKERS", "4"))))
+    ahead = 2 * workers
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        loads = deque(pool.submit(load, gi) for gi in mine[:ahead])
+        done = []
+        for k, gi in enumerate(mine):
+            img = loads.popleft().result()
+            if k + ahead < len(mine):
+                loads.append(pool.submit(load, mine[k + ahead]))
+            x = torch.from_numpy(img)[None].to(dev)                  # uint8 NHWC; normalised on device
+            labels, counts = model.predict_labels(x, exclude_nodes=False, labels_dtype=torch.uint8)
+            lab = labels[0].cpu().numpy()
+            cnt = (int(counts[0, 1]), int(counts[0, 2]))
+            done.append(pool.submit(finish, gi, lab, cnt))
+        for k, f in enumerate(done):
+            rows[k] = f.result()
 
     allrows = gather_rows(rows, len(images), world, dist, dev)
     if rank == 0:
