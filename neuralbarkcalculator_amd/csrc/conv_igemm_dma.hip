@@ -635,7 +635,7 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   7   128x64    2x2            64x32      2       48 KiB   3   (short-K layers: K fits two stages)
 //   8   64x128    1x4            64x32      2       48 KiB   3
 //   9   128x128   4x2            32x64      2       70 KiB   2   (8 waves: short-K layers, where the
-//   10  128x64    4x2            32x32      2       48 KiB   2    serial prologue/epilogue code dominates
+//   10  128x64    4x2            32x32      2       48 KiB   3    serial prologue/epilogue code dominates
 //   11  256x128   4x4            64x32      2       96 KiB   1    and more waves run it in parallel)
 template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
