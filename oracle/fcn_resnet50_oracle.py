@@ -27,7 +27,10 @@ path, and its modules cannot be imported here (ordinary
 ``ModuleNotFoundError: torchvision``).  **parity unpinned** by reference fixtures; the
 independent pins are (tests/test_oracle.py): the 326 state_dict key names, the
 32 947 779 parameter count, the feature-map shapes, and the closed-form bicubic
-weights.  Goldens under tests/golden/ are produced by THIS file (drift guards).
+weights, and ``oracle/numpy_restatement.py`` — the same forward written again in
+float64 numpy from the published formulas, sharing no code with this file — which
+agrees with this file to 2e-5 of the logit range on a ragged 40x56 input.  Goldens
+under tests/golden/ are produced by THIS file (drift guards).
 
 Decision D1: the oracle runs in eval mode (BN running stats,
 Dropout identity).  ``predict.py`` as shipped never calls ``.eval()`` and is therefore

@@ -113,3 +113,25 @@ def test_exclude_nodes_remap(oracle_model):
     assert int((l1 == 2).sum()) == 0
     assert (l1[l0 == 2] == 1).all() and (l1[l0 != 2] == l0[l0 != 2]).all()
     assert c1[0].tolist() == [int(c0[0, 0]), int(c0[0, 1] + c0[0, 2]), 0]
+
+
+def test_numpy_restatement_agrees_with_torch_oracle(oracle_model, sd_np):
+    """The torch-based oracle against a float64 numpy restatement that shares no code with it
+    (oracle/numpy_restatement.py): topology wiring, stride/dilation placement, eval BatchNorm, -inf
+    padded max-pooling, the unclamped bicubic source coordinate with clamped taps, first-maximum argmax.
+    A 40x56 input: not a multiple of the stride-8 grid, so every floor in the size formulas is exercised."""
+    import torch
+    from oracle import numpy_restatement as npr
+    from oracle.fcn_resnet50_oracle import predict_labels
+    from neuralbarkcalculator_amd import synth
+    x = synth.make_input(5, 40, 56)
+    low, logits, labels = npr.forward(sd_np, x)
+    labels_t, _, logits_t, lowres_t = predict_labels(oracle_model, torch.from_numpy(x)[None])
+    assert low.shape == tuple(lowres_t.shape[1:]) == (3, 5, 7)
+    scale = float(np.abs(low).max())
+    assert float(np.abs(low - lowres_t[0].numpy()).max()) <= 2e-5 * scale
+    assert float(np.abs(logits - logits_t[0].numpy()).max()) <= 2e-5 * scale
+    top2 = np.sort(logits, axis=0)
+    clear = (top2[2] - top2[1]) > 1e-4 * scale            # away from float32-vs-float64 ties
+    assert clear.mean() > 0.99
+    assert np.array_equal(labels[clear], labels_t[0].numpy()[clear])
