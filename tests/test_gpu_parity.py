@@ -381,3 +381,19 @@ def test_overlapped_forwards_on_four_streams(gpu_fp32, gpu_bf16, mode):
                 assert torch.equal(got, want), f"stream {k} differs from the same frame alone ({mode})"
     finally:
         model.autotune(xs[0], objective="latency")
+
+
+def test_fp32_against_the_numpy_restatement(gpu_fp32, sd_np):
+    """The HIP fp32 path against the float64 numpy restatement directly (no torch operator on the
+    checking side): low-res logits within the fp32 tolerance, labels equal away from ties."""
+    from oracle import numpy_restatement as npr
+    x = synth.make_input(5, 40, 56)
+    low, logits, labels_np = npr.forward(sd_np, x)
+    labels, counts, lowres = gpu_fp32.predict_labels(torch.from_numpy(x)[None].to(DEV), return_lowres=True)
+    full = gpu_fp32(torch.from_numpy(x)[None].to(DEV))[0].cpu().numpy()
+    scale = float(np.abs(low).max())
+    assert float(np.abs(lowres[0].cpu().numpy() - low).max()) <= LOGIT_RTOL_FP32 * scale
+    assert float(np.abs(full - logits).max()) <= LOGIT_RTOL_FP32 * scale
+    top2 = np.sort(logits, axis=0)
+    clear = (top2[2] - top2[1]) > 1e-4 * scale
+    assert np.array_equal(labels[0].cpu().numpy()[clear], labels_np[clear])
