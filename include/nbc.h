@@ -148,6 +148,17 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
                         float* logits_full_dev, void* labels_dev, int labels_dtype,
                         int64_t* counts_dev, int exclude_nodes, void* hip_stream);
 
+/* remove_small_zones of utils.py:135-148 (called at models.py:271, between the argmax and the
+ * statistics) on device labels, in place: with m = (labels == 0), 8-connected components of ~m smaller
+ * than min_pixels join m (skimage remove_small_holes, connectivity=2), then 8-connected components of
+ * the filled m smaller than min_pixels leave it (remove_small_objects); pixels that left m and were
+ * class 0 become class 1, pixels that joined it become class 0.  The reference uses 150 pixels.
+ * labels_dev: uint8 or int64 [N,H,W] (labels_dtype NBC_LABEL_U8 / NBC_LABEL_I64).  exclude_nodes
+ * applies the 2 -> 1 remap of models.py:273-276 afterwards; counts_dev (nullable, int64 [N,3]) receives
+ * the pixels per class of the result (the counting of models.py:324-331).  N <= 85. */
+int nbc_remove_small_zones(nbc_ctx* ctx, void* labels_dev, int labels_dtype, int N, int H, int W, int min_pixels,
+                           int exclude_nodes, int64_t* counts_dev, void* hip_stream);
+
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
  * register-staged reference kernel; tile = -1 (per-layer choice) or 0..11 = 128x64, 128x128,
  * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave

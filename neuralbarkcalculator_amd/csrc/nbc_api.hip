@@ -74,6 +74,8 @@ struct nbc_ctx {
   std::vector<Op> prof_ops;
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
+  void* zones_ws = nullptr;                 // remove_small_zones workspace: bg bytes, parent ints, size ints
+  size_t zones_px = 0;                      // pixels it is sized for
 };
 
 namespace {
@@ -291,6 +293,7 @@ int nbc_destroy(nbc_ctx* c) {
   for (void* b : c->bufs) if (b) (void)hipFree(b);
   if (c->lowres) (void)hipFree(c->lowres);
   if (c->zero_page) (void)hipFree(c->zero_page);
+  if (c->zones_ws) (void)hipFree(c->zones_ws);
   if (c->owned_weights) (void)hipFree(c->owned_weights);
   for (auto& set : c->prof_sets) for (hipEvent_t ev : set) (void)hipEventDestroy(ev);
   delete c;
@@ -545,6 +548,27 @@ int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, in
   NBC_HIP(launch_upsample_argmax(lowres, N, h, w, H, W, logits_full_dev, labels_dev,
                                  labels_dtype == NBC_LABEL_I64 ? 1 : 0,
                                  reinterpret_cast<unsigned long long*>(counts_dev), exclude_nodes, s));
+  return NBC_OK;
+}
+
+int nbc_remove_small_zones(nbc_ctx* c, void* labels_dev, int labels_dtype, int N, int H, int W, int min_pixels,
+                           int exclude_nodes, int64_t* counts_dev, void* hip_stream) {
+  if (!c || !labels_dev) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: null argument");
+  if (N < 1 || N > 85 || H < 1 || W < 1 || min_pixels < 0) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: bad shape");
+  if (labels_dtype != NBC_LABEL_U8 && labels_dtype != NBC_LABEL_I64) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: bad labels_dtype");
+  NBC_HIP(hipSetDevice(c->device));
+  const size_t px = (size_t)N * H * W;
+  if (px > c->zones_px) {
+    if (c->zones_ws) { NBC_HIP(hipFree(c->zones_ws)); c->zones_ws = nullptr; c->zones_px = 0; }
+    NBC_HIP(hipMalloc(&c->zones_ws, px * 9 + 256));
+    c->zones_px = px;
+  }
+  int* parent = static_cast<int*>(c->zones_ws);
+  int* size = parent + px;
+  unsigned char* bg = reinterpret_cast<unsigned char*>(size + px);
+  NBC_HIP(launch_remove_small_zones(labels_dev, labels_dtype == NBC_LABEL_I64 ? 1 : 0, N, H, W, min_pixels, exclude_nodes, bg,
+                                    parent, size, reinterpret_cast<unsigned long long*>(counts_dev),
+                                    static_cast<hipStream_t>(hip_stream)));
   return NBC_OK;
 }
 

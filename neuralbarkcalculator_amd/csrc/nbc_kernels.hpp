@@ -60,6 +60,11 @@ hipError_t launch_head1x1(const void* x, const float* w, const float* bias, floa
 hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int H, int W,
                                   float* logits_full, void* labels, int labels_i64,
                                   unsigned long long* counts, int exclude_nodes, hipStream_t s);
+// remove_small_zones (utils.py:135-148) in place on device labels (u8 or i64, [N,H,W]): 8-connected
+// components below min_pixels of the non-background, then of the filled background, flip; optional
+// 2 -> 1 remap and per-class counts afterwards.  Workspaces: bg N*H*W bytes, parent and size N*H*W ints.
+hipError_t launch_remove_small_zones(void* labels, int labels_i64, int N, int H, int W, int min_pixels, int exclude_nodes,
+                                     unsigned char* bg, int* parent, int* size, unsigned long long* counts, hipStream_t s);
 // NHWC elements -> float32 NCHW (debug read-back of activations).
 hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W, int C, int precision,
                                    hipStream_t s);

@@ -159,6 +159,28 @@ class FCNResNet50:
         self._forward(x, n, h, w, lowres=lowres)
         return lowres
 
+    def remove_small_zones(self, labels: torch.Tensor, exclude_nodes: bool = False, min_pixels: int = 150):
+        """``utils.remove_small_zones`` (utils.py:135-148, called at models.py:271) on the device, IN PLACE
+        on ``labels`` (uint8 or int64 ``[N,H,W]`` / ``[H,W]`` on this model's device): 8-connected zones
+        of fewer than ``min_pixels`` pixels of the non-background, then of the filled background, flip
+        (class 0 <-> class 1).  ``exclude_nodes`` applies the 2 -> 1 remap of models.py:273-276
+        afterwards.  Returns ``(labels, counts int64 [N,3])`` with the pixels per class of the result."""
+        self._require_ctx()
+        if labels.device != self.device or labels.dtype not in (torch.uint8, torch.int64) or not labels.is_contiguous():
+            raise ValueError("labels must be a contiguous uint8 or int64 tensor on %s" % (self.device,))
+        if labels.dim() not in (2, 3):
+            raise ValueError("labels must be [H,W] or [N,H,W]")
+        n = 1 if labels.dim() == 2 else int(labels.shape[0])
+        h, w = int(labels.shape[-2]), int(labels.shape[-1])
+        counts = torch.empty((n, 3), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.nbc_remove_small_zones(self._ctx, labels.data_ptr(),
+                                                        _lib.LABEL_I64 if labels.dtype == torch.int64 else _lib.LABEL_U8,
+                                                        n, h, w, int(min_pixels), int(bool(exclude_nodes)),
+                                                        counts.data_ptr(), stream), "nbc_remove_small_zones")
+        return labels, counts
+
     def upsample_argmax(self, lowres: torch.Tensor, size: Tuple[int, int], exclude_nodes: bool = False,
                         labels_dtype: torch.dtype = torch.int64, return_logits: bool = False):
         """Tail of the path on caller-supplied low-res logits f32 ``[N,3,h,w]``:

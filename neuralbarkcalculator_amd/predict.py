@@ -200,8 +200,6 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     import torch
     from PIL import Image
     from .model import FCNResNet50
-    from .postprocess import remove_small_zones
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if device_index is None else device_index
@@ -231,10 +229,10 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     mine = shard_indices(len(images), rank, world)
     rows = np.zeros((len(mine), ROW_WIDTH), dtype=np.int64)
 
-    # The forward is ~1.4 ms per image; decoding the PNG, removing small zones and writing the label
-    # PNG are tens of milliseconds of host work each.  They run on a small thread pool around the GPU
-    # loop (PIL, numpy and scipy release the GIL in their C code): a few images are decoded ahead and
-    # every image's post-processing is handed off as soon as its labels are on the host.
+    # The forward is ~1.4 ms per image and remove_small_zones ~0.6 ms on the device; decoding the PNG
+    # and writing the label PNG are tens of milliseconds of host work each.  They run on a small
+    # thread pool around the GPU loop (PIL and numpy release the GIL in their C code): a few images are
+    # decoded ahead and every image's PNG is handed off as soon as its labels are on the host.
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
 
@@ -244,16 +242,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
 
     def finish(gi, lab, counts):
         _, name, wood = images[gi]
-        if small_zones:                                              # models.py:271
-            lab = remove_small_zones(lab)
-        if exclude_nodes:                                            # models.py:273-276
-            lab[lab == 2] = 1
-        if small_zones or exclude_nodes:
-            c1, c2 = int((lab == 1).sum()), int((lab == 2).sum())
-        else:
-            c1, c2 = counts
         Image.fromarray(label_png(lab), mode="L").save(os.path.join(root, "results", "outputs", wood, name))
-        return (gi, lab.shape[0], lab.shape[1], c1, c2)
+        return (gi, lab.shape[0], lab.shape[1], counts[0], counts[1])
 
     workers = max(1, min(8, int(os.environ.get("NBC_HOST_WORKERS", "4"))))
     ahead = 2 * workers
@@ -265,7 +255,10 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
             if k + ahead < len(mine):
                 loads.append(pool.submit(load, mine[k + ahead]))
             x = torch.from_numpy(img)[None].to(dev)                  # uint8 NHWC; normalised on device
-            labels, counts = model.predict_labels(x, exclude_nodes=False, labels_dtype=torch.uint8)
+            labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes and not small_zones,
+                                                  labels_dtype=torch.uint8)
+            if small_zones:                                          # models.py:271, then :273-276, on the device
+                labels, counts = model.remove_small_zones(labels, exclude_nodes=exclude_nodes)
             lab = labels[0].cpu().numpy()
             cnt = (int(counts[0, 1]), int(counts[0, 2]))
             done.append(pool.submit(finish, gi, lab, cnt))

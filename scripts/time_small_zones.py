@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""remove_small_zones: GPU (nbc_remove_small_zones) vs the CPU restatement on network labels of a 1024^2 frame."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+from neuralbarkcalculator_amd import synth
+from neuralbarkcalculator_amd.model import FCNResNet50
+from neuralbarkcalculator_amd.postprocess import remove_small_zones
+
+dev = torch.device("cuda:0")
+torch.set_num_threads(16)
+m = FCNResNet50("bf16").load_state_dict(synth.make_state_dict("trained_like", seed=7)).to(dev)
+x = torch.from_numpy(synth.make_input(0, 1024, 1024))[None].to(dev)
+labels, _ = m.predict_labels(x, labels_dtype=torch.uint8)
+lab_np = labels.cpu().numpy()
+t0 = time.perf_counter(); want = remove_small_zones(lab_np); t_cpu = time.perf_counter() - t0
+work = [labels.clone() for _ in range(52)]
+for w in work[:2]:
+    m.remove_small_zones(w)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for w in work[2:]:
+    m.remove_small_zones(w)
+e1.record(); torch.cuda.synchronize()
+t_gpu = e0.elapsed_time(e1) / 50
+assert np.array_equal(work[-1].cpu().numpy(), want)
+changed = int((want != lab_np).sum())
+print(f"remove_small_zones 1024x1024: GPU {t_gpu * 1e3:.0f} us (8 launches + memset), CPU restatement {t_cpu * 1e3:.1f} ms, "
+      f"{changed} pixels changed, results identical; 9 bytes/pixel workspace, ~40 B/pixel of traffic -> {40 * 1024 * 1024 / (t_gpu * 1e-3) / 1e12:.2f} TB/s")

@@ -1,0 +1,104 @@
+"""remove_small_zones on the GPU (csrc/small_zones.hip, nbc_remove_small_zones) against the scikit-image
+0.18.3 fixtures and against the CPU restatement (postprocess.remove_small_zones, itself pinned by the
+same fixtures).  Integer work: every comparison is exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from neuralbarkcalculator_amd import synth
+from neuralbarkcalculator_amd.model import FCNResNet50
+from neuralbarkcalculator_amd.postprocess import remove_small_zones
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def model(built_lib, sd_np):
+    return FCNResNet50("bf16").load_state_dict(sd_np).to(DEV)
+
+
+def run_gpu(model, labels_np, dtype=torch.uint8, exclude_nodes=False, min_pixels=150):
+    t = torch.from_numpy(np.ascontiguousarray(labels_np)).to(dtype).to(DEV)
+    out, counts = model.remove_small_zones(t, exclude_nodes=exclude_nodes, min_pixels=min_pixels)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), counts.cpu().numpy()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "small_zones_*.npz"))))
+def test_skimage_fixtures(model, path):
+    g = np.load(path, allow_pickle=False)
+    for dtype in (torch.uint8, torch.int64):
+        out, counts = run_gpu(model, g["labels"], dtype)
+        np.testing.assert_array_equal(out.astype(g["expected"].dtype), g["expected"])
+        exp = g["expected"]
+        assert counts.tolist() == [[int((exp == c).sum()) for c in range(3)]]
+    again, _ = run_gpu(model, g["expected"])                      # idempotent
+    np.testing.assert_array_equal(again.astype(g["expected"].dtype), g["expected"])
+
+
+def blobs(seed, n, h, w, p_bg, smooth):
+    """Random class maps with zones of every size: thresholded smoothed noise plus salt."""
+    rng = np.random.default_rng(seed)
+    f = rng.standard_normal((n, h, w))
+    for _ in range(smooth):
+        f = (f + np.roll(f, 1, 1) + np.roll(f, -1, 1) + np.roll(f, 1, 2) + np.roll(f, -1, 2)) / 5.0
+    q = np.quantile(f, [p_bg, p_bg + (1 - p_bg) * 0.6])
+    lab = np.where(f < q[0], 0, np.where(f < q[1], 1, 2)).astype(np.uint8)
+    salt = rng.random((n, h, w)) < 0.01
+    lab[salt] = rng.integers(0, 3, size=int(salt.sum()), dtype=np.uint8)
+    return lab
+
+
+@pytest.mark.parametrize("shape,p_bg,smooth", [((1, 1024, 1024), 0.8, 6), ((3, 200, 333), 0.5, 3), ((2, 33, 95), 0.3, 1),
+                                              ((1, 31, 31), 0.5, 0), ((1, 64, 1), 0.5, 0), ((1, 520, 1024), 0.1, 8)])
+def test_random_maps_equal_cpu_restatement(model, shape, p_bg, smooth):
+    n, h, w = shape
+    lab = blobs(sum(shape), n, h, w, p_bg, smooth)
+    want = remove_small_zones(lab)
+    got, counts = run_gpu(model, lab)
+    np.testing.assert_array_equal(got, want)
+    assert counts.tolist() == [[int((want[i] == c).sum()) for c in range(3)] for i in range(n)]
+    want_x = want.copy(); want_x[want_x == 2] = 1                 # models.py:273-276 after the zones
+    got_x, counts_x = run_gpu(model, lab, torch.int64, exclude_nodes=True)
+    np.testing.assert_array_equal(got_x, want_x)
+    assert counts_x[:, 2].tolist() == [0] * n
+    for mp in (1, 2, 37, 5000):                                    # other thresholds, same algorithm
+        np.testing.assert_array_equal(run_gpu(model, lab, min_pixels=mp)[0], remove_small_zones(lab, mp))
+
+
+def test_worst_case_shapes(model):
+    """Components that wind through many 32x32 tiles: a one-pixel spiral, a comb, a checkerboard
+    (8-connected: one component of half the pixels), all-zero and all-one maps."""
+    h = w = 256
+    cases = []
+    spiral = np.zeros((h, w), np.uint8)
+    y0, x0, y1, x1 = 0, 0, h - 1, w - 1
+    while y0 <= y1 and x0 <= x1:
+        spiral[y0, x0:x1 + 1] = 1; spiral[y0:y1 + 1, x1] = 1
+        if y1 > y0: spiral[y1, x0 + 2:x1 + 1] = 1
+        if x1 > x0 + 2: spiral[y0 + 2:y1 + 1, x0 + 2] = 1
+        y0 += 2; x0 += 2; y1 -= 2; x1 -= 2
+    cases.append(spiral)
+    comb = np.zeros((h, w), np.uint8); comb[:, ::2] = 2; comb[0, :] = 2
+    cases.append(comb)
+    yy, xx = np.mgrid[0:h, 0:w]
+    cases.append(((yy + xx) % 2).astype(np.uint8))
+    cases.append(np.zeros((h, w), np.uint8))
+    cases.append(np.ones((h, w), np.uint8))
+    for lab in cases:
+        np.testing.assert_array_equal(run_gpu(model, lab)[0], remove_small_zones(lab))
+        np.testing.assert_array_equal(run_gpu(model, 1 - np.minimum(lab, 1))[0], remove_small_zones(1 - np.minimum(lab, 1)))
+
+
+def test_on_network_labels(model):
+    x = torch.from_numpy(np.stack([synth.make_input(60 + k, 512, 512) for k in range(2)])).to(DEV)
+    labels, _ = model.predict_labels(x, labels_dtype=torch.uint8)
+    want = remove_small_zones(labels.cpu().numpy())
+    got, counts = model.remove_small_zones(labels.clone())
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert int(counts.sum()) == labels.numel()
