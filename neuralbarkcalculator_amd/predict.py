@@ -229,7 +229,7 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     mine = shard_indices(len(images), rank, world)
     rows = np.zeros((len(mine), ROW_WIDTH), dtype=np.int64)
 
-    # The forward is ~1.4 ms per image and remove_small_zones ~0.6 ms on the device; decoding the PNG
+    # The forward is ~1.4 ms per image and remove_small_zones ~0.14 ms on the device; decoding the PNG
     # and writing the label PNG are tens of milliseconds of host work each.  They run on a small
     # thread pool around the GPU loop (PIL and numpy release the GIL in their C code): a few images are
     # decoded ahead and every image's PNG is handed off as soon as its labels are on the host.

@@ -102,3 +102,21 @@ def test_on_network_labels(model):
     got, counts = model.remove_small_zones(labels.clone())
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     assert int(counts.sum()) == labels.numel()
+
+
+def test_many_random_small_maps(model):
+    """Tile-border rules (runs touching across horizontal / vertical borders, diagonals through tile
+    corners): 300 random maps of random sizes around the 32-pixel tile grid, several densities and
+    thresholds; every result equals the CPU restatement."""
+    rng = np.random.default_rng(2024)
+    for k in range(300):
+        h = int(rng.integers(1, 100)); w = int(rng.integers(1, 100))
+        if k % 7 == 0:
+            h, w = int(rng.choice([31, 32, 33, 63, 64, 65])), int(rng.choice([31, 32, 33, 63, 64, 65, 96]))
+        dens = float(rng.choice([0.1, 0.3, 0.5, 0.59, 0.7, 0.9]))     # 0.59: near the percolation threshold, long winding components
+        lab = (rng.random((h, w)) > dens).astype(np.uint8) * rng.integers(1, 3, size=(h, w), dtype=np.uint8)
+        mp = int(rng.choice([2, 5, 20, 150, 1000]))
+        want = remove_small_zones(lab, mp)
+        got, counts = run_gpu(model, lab, min_pixels=mp)
+        assert np.array_equal(got, want), f"case {k}: {h}x{w} density {dens} threshold {mp}: {int((got != want).sum())} pixels differ"
+        assert counts.tolist() == [[int((want == c).sum()) for c in range(3)]]
