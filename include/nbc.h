@@ -159,6 +159,14 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
 int nbc_remove_small_zones(nbc_ctx* ctx, void* labels_dev, int labels_dtype, int N, int H, int W, int min_pixels,
                            int exclude_nodes, int64_t* counts_dev, void* hip_stream);
 
+/* The resize of the reference's preprocessor (models.py:191-198): uint8 RGB [H,W,3] on the device ->
+ * ToTensor (u8 / 255 in float32) -> skimage.transform.resize(order=3, mode='reflect',
+ * anti_aliasing=False) to out_h x out_w (4-tap Catmull-Rom at factor*(i+0.5)-0.5, reflected borders,
+ * clipped to the input range) -> float32 [out_h,out_w,3] on the device.  Bit-identical to the numpy
+ * restatement in neuralbarkcalculator_amd/predict.py, which scikit-image 0.18.3 fixtures pin. */
+int nbc_resize_cubic_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, float* dst_dev, int out_h, int out_w,
+                        void* hip_stream);
+
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
  * register-staged reference kernel; tile = -1 (per-layer choice) or 0..11 = 128x64, 128x128,
  * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave

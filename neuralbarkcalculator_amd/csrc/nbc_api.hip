@@ -74,6 +74,7 @@ struct nbc_ctx {
   std::vector<Op> prof_ops;
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
+  void* scratch256 = nullptr;               // 256 bytes of device scratch (min/max of the preprocessor resize)
   void* zones_ws = nullptr;                 // remove_small_zones workspace: bg bytes, parent ints, size ints
   size_t zones_px = 0;                      // pixels it is sized for
 };
@@ -294,6 +295,7 @@ int nbc_destroy(nbc_ctx* c) {
   if (c->lowres) (void)hipFree(c->lowres);
   if (c->zero_page) (void)hipFree(c->zero_page);
   if (c->zones_ws) (void)hipFree(c->zones_ws);
+  if (c->scratch256) (void)hipFree(c->scratch256);
   if (c->owned_weights) (void)hipFree(c->owned_weights);
   for (auto& set : c->prof_sets) for (hipEvent_t ev : set) (void)hipEventDestroy(ev);
   delete c;
@@ -569,6 +571,17 @@ int nbc_remove_small_zones(nbc_ctx* c, void* labels_dev, int labels_dtype, int N
   NBC_HIP(launch_remove_small_zones(labels_dev, labels_dtype == NBC_LABEL_I64 ? 1 : 0, N, H, W, min_pixels, exclude_nodes, bg,
                                     parent, size, reinterpret_cast<unsigned long long*>(counts_dev),
                                     static_cast<hipStream_t>(hip_stream)));
+  return NBC_OK;
+}
+
+int nbc_resize_cubic_u8(nbc_ctx* c, const uint8_t* src_dev, int H, int W, float* dst_dev, int out_h, int out_w,
+                        void* hip_stream) {
+  if (!c || !src_dev || !dst_dev) return set_error(NBC_ERR_INVALID, "nbc_resize_cubic_u8: null argument");
+  if (H < 1 || W < 1 || out_h < 1 || out_w < 1) return set_error(NBC_ERR_INVALID, "nbc_resize_cubic_u8: bad shape");
+  NBC_HIP(hipSetDevice(c->device));
+  if (!c->scratch256) NBC_HIP(hipMalloc(&c->scratch256, 256));
+  unsigned* minmax = static_cast<unsigned*>(c->scratch256);
+  NBC_HIP(launch_resize_cubic_u8(src_dev, H, W, dst_dev, out_h, out_w, minmax, static_cast<hipStream_t>(hip_stream)));
   return NBC_OK;
 }
 

@@ -418,6 +418,74 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restric
   }
 }
 
+// ---- preprocessor (next-row N4): models.py:191-198, skimage.transform.resize(order=3, mode='reflect',
+// anti_aliasing=False) of the ToTensor'd image, as restated and pinned in neuralbarkcalculator_amd/predict.py
+// (resize_bicubic_reflect): output pixel i samples the input at factor*(i+0.5)-0.5 with a separable
+// 4-tap Catmull-Rom kernel, reflected borders, clipped to the input range.  Every rounding of the numpy
+// restatement is reproduced (coordinates and offsets in f32, the two value differences in f32, the
+// polynomial in f64 without contraction, each pass rounded to f32), so the output is bit-identical.
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  if (n == 1) return 0;
+  const int period = 2 * (n - 1);
+  i %= period;
+  if (i < 0) i += period;
+  return i >= n ? period - i : i;
+}
+__device__ __forceinline__ float cubic_f32(double x, float f0, float f1, float f2, float f3) {
+  const double d20 = (double)__fsub_rn(f2, f0), d12 = (double)__fsub_rn(f1, f2);
+  const double a0 = f0, a1 = f1, a2 = f2, a3 = f3;
+  // f1 + 0.5*x*(d20 + x*(2*f0 - 5*f1 + 4*f2 - f3 + x*(3*d12 + f3 - f0))), numpy's left-to-right order
+  const double inner = __dsub_rn(__dadd_rn(__dmul_rn(3.0, d12), a3), a0);
+  const double mid = __dadd_rn(__dsub_rn(__dadd_rn(__dsub_rn(__dmul_rn(2.0, a0), __dmul_rn(5.0, a1)), __dmul_rn(4.0, a2)), a3),
+                               __dmul_rn(x, inner));
+  const double outer = __dadd_rn(d20, __dmul_rn(x, mid));
+  return (float)__dadd_rn(a1, __dmul_rn(__dmul_rn(0.5, x), outer));
+}
+
+__global__ void minmax_u8_kernel(const uint8_t* __restrict__ x, size_t n, unsigned* __restrict__ mm) {
+  unsigned lo = 255u, hi = 0u;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned v = x[i];
+    lo = v < lo ? v : lo;
+    hi = v > hi ? v : hi;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+}
+
+// grid = (ceil(out_w*3 / 256), out_h); a thread owns one channel of one output pixel
+__global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __restrict__ src, int H, int W, float* __restrict__ dst,
+                                                           int out_h, int out_w, const unsigned* __restrict__ mm) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int ox = e / 3, c = e - ox * 3, oy = blockIdx.y;
+  if (ox >= out_w) return;
+  const float ry = (float)__dsub_rn(__dmul_rn(__ddiv_rn((double)H, (double)out_h), __dadd_rn((double)oy, 0.5)), 0.5);
+  const float rx = (float)__dsub_rn(__dmul_rn(__ddiv_rn((double)W, (double)out_w), __dadd_rn((double)ox, 0.5)), 0.5);
+  const int y0 = (int)floorf(ry), x0 = (int)floorf(rx);
+  const double ty = (double)__fsub_rn(ry, (float)y0), tx = (double)__fsub_rn(rx, (float)x0);
+  int cols[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) cols[k] = reflect_index(x0 + k - 1, W);
+  float fr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint8_t* row = src + (size_t)reflect_index(y0 + k - 1, H) * W * 3 + c;
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = __fdiv_rn((float)row[(size_t)cols[j] * 3], 255.0f);      // ToTensor
+    fr[k] = cubic_f32(tx, f[0], f[1], f[2], f[3]);
+  }
+  float v = cubic_f32(ty, fr[0], fr[1], fr[2], fr[3]);
+  const float lo = __fdiv_rn((float)mm[0], 255.0f), hi = __fdiv_rn((float)mm[1], 255.0f);
+  v = v < lo ? lo : (v > hi ? hi : v);                     // np.clip(out, img.min(), img.max())
+  dst[((size_t)oy * out_w + ox) * 3 + c] = v;
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   const size_t cap = 256 * 8;                 // 8 blocks per CU, grid-stride the rest
@@ -493,6 +561,19 @@ hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int 
     hipLaunchKernelGGL(upsample_argmax_kernel, grid, dim3(256), 0, s, lowres, h, w, H, W, scale_y, scale_x,
                        logits_full, labels, labels_i64, counts, exclude_nodes);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, int out_h, int out_w, unsigned* minmax,
+                                  hipStream_t s) {
+  if (H < 1 || W < 1 || out_h < 1 || out_w < 1 || out_h > 65535) return hipErrorInvalidValue;
+  const unsigned init[2] = {255u, 0u};
+  hipError_t e = hipMemcpyAsync(minmax, init, sizeof(init), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  const size_t n = (size_t)H * W * 3;
+  hipLaunchKernelGGL(minmax_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, n, minmax);
+  hipLaunchKernelGGL(resize_cubic_kernel, dim3((out_w * 3 + 255) / 256, out_h), dim3(256), 0, s, src, H, W, dst, out_h, out_w,
+                     minmax);
   return hipGetLastError();
 }
 

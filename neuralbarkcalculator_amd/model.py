@@ -181,6 +181,22 @@ class FCNResNet50:
                                                         counts.data_ptr(), stream), "nbc_remove_small_zones")
         return labels, counts
 
+    def resize_cubic_u8(self, image: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+        """The resize of the reference's preprocessor (models.py:191-198) on the device: uint8 RGB
+        ``[H,W,3]`` -> ToTensor -> ``skimage.transform.resize(order=3, mode='reflect',
+        anti_aliasing=False)`` -> float32 ``[out_h,out_w,3]``; bit-identical to
+        ``predict.resize_bicubic_reflect(image.astype(float32) / 255, out_h, out_w)``."""
+        self._require_ctx()
+        if image.device != self.device or image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3 \
+                or not image.is_contiguous():
+            raise ValueError("image must be a contiguous uint8 [H,W,3] tensor on %s" % (self.device,))
+        out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.nbc_resize_cubic_u8(self._ctx, image.data_ptr(), int(image.shape[0]), int(image.shape[1]),
+                                                     out.data_ptr(), int(out_h), int(out_w), stream), "nbc_resize_cubic_u8")
+        return out
+
     def upsample_argmax(self, lowres: torch.Tensor, size: Tuple[int, int], exclude_nodes: bool = False,
                         labels_dtype: torch.dtype = torch.int64, return_logits: bool = False):
         """Tail of the path on caller-supplied low-res logits f32 ``[N,3,h,w]``:

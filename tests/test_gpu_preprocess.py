@@ -1,0 +1,58 @@
+"""The preprocessor's resize on the GPU (nbc_resize_cubic_u8, models.py:191-198) against the numpy
+restatement (bit for bit) and the scikit-image 0.18.3 fixtures (same tolerance as the CPU test)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from neuralbarkcalculator_amd import predict as drv
+from neuralbarkcalculator_amd.model import FCNResNet50
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def model(built_lib):
+    return FCNResNet50("bf16").to(DEV)            # no weights needed for the preprocessor
+
+
+@pytest.mark.parametrize("shape,out", [((2048, 2048), (1024, 1024)), ((1500, 1100), (1024, 1024)), ((1025, 1025), (1024, 1024)),
+                                       ((3000, 512), (1024, 1024)), ((5, 7), (3, 4)), ((1, 9), (4, 4)), ((40, 1030), (64, 64)),
+                                       ((333, 777), (100, 50))])
+def test_resize_equals_numpy_restatement(model, shape, out):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    img = rng.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+    img[: shape[0] // 3] //= 4                                  # a darker band: clipping bounds below 255
+    want = drv.resize_bicubic_reflect(img.astype(np.float32) / np.float32(255), out[0], out[1])
+    got = model.resize_cubic_u8(torch.from_numpy(img).to(DEV), out[0], out[1]).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got, want), f"{int((got != want).sum())} of {got.size} values differ, max {np.abs(got - want).max()}"
+
+
+def test_constant_and_extreme_images(model):
+    for v in (0, 255, 17):
+        img = np.full((70, 90, 3), v, np.uint8)
+        got = model.resize_cubic_u8(torch.from_numpy(img).to(DEV), 32, 32).cpu().numpy()
+        assert np.array_equal(got, drv.resize_bicubic_reflect(img.astype(np.float32) / np.float32(255), 32, 32))
+
+
+def test_preprocess_image_with_and_without_device(model):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(1300, 1300, 3), dtype=np.uint8)
+    img[:200] = 0                                               # black rows: trim_black has something to do
+    a = drv.preprocess_image(img, 1024)
+    b = drv.preprocess_image(img, 1024, model)
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "preprocess_*.npz"))))
+def test_skimage_fixtures_through_the_device(model, path):
+    g = np.load(path, allow_pickle=False)
+    out = drv.preprocess_image(g["image"], int(g["target"]), model)
+    assert out.shape == g["expected"].shape and out.dtype == np.uint8
+    diff = np.abs(out.astype(np.int16) - g["expected"].astype(np.int16))
+    assert diff.max() <= 1 and (diff > 0).mean() < 2e-2        # exact x.5 ties only, as in tests/test_driver.py
