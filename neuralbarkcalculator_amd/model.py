@@ -135,8 +135,10 @@ class FCNResNet50:
     # ---- fused extras ---------------------------------------------------------------------
     def predict_labels(self, x: torch.Tensor, exclude_nodes: bool = False,
                        labels_dtype: torch.dtype = torch.int64,
-                       return_lowres: bool = False):
+                       return_lowres: bool = False, small_zones: bool = False):
         """Model call + argmax (+ optional 2->1 remap) + per-class pixel counts in one pass.
+        ``small_zones=True`` also applies ``remove_small_zones`` (models.py:271) on the device, before
+        the remap like the reference does (models.py:271-276); the counts are those of the final labels.
 
         Returns ``(labels [N,H,W], counts int64 [N,3])`` (+ ``lowres f32 [N,3,h,w]``)."""
         n, h, w = self._check_input(x)
@@ -148,7 +150,10 @@ class FCNResNet50:
         if return_lowres:
             lh, lw = out_hw(h, w)
             lowres = torch.empty((n, NUM_CLASSES, lh, lw), dtype=torch.float32, device=self.device)
-        self._forward(x, n, h, w, labels=labels, counts=counts, lowres=lowres, exclude_nodes=exclude_nodes)
+        self._forward(x, n, h, w, labels=labels, counts=counts, lowres=lowres,
+                      exclude_nodes=exclude_nodes and not small_zones)
+        if small_zones:
+            labels, counts = self.remove_small_zones(labels, exclude_nodes=exclude_nodes)
         return (labels, counts, lowres) if return_lowres else (labels, counts)
 
     def lowres_logits(self, x: torch.Tensor) -> torch.Tensor:

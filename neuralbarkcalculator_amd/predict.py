@@ -278,10 +278,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
             if k + ahead < len(mine):
                 loads.append(pool.submit(load, mine[k + ahead]))
             x = torch.from_numpy(img)[None].to(dev)                  # uint8 NHWC; normalised on device
-            labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes and not small_zones,
-                                                  labels_dtype=torch.uint8)
-            if small_zones:                                          # models.py:271, then :273-276, on the device
-                labels, counts = model.remove_small_zones(labels, exclude_nodes=exclude_nodes)
+            labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes, labels_dtype=torch.uint8,
+                                                  small_zones=small_zones)   # models.py:269-276 on the device
             lab = labels[0].cpu().numpy()
             cnt = (int(counts[0, 1]), int(counts[0, 2]))
             done.append(pool.submit(finish, gi, lab, cnt))

@@ -120,3 +120,17 @@ def test_many_random_small_maps(model):
         got, counts = run_gpu(model, lab, min_pixels=mp)
         assert np.array_equal(got, want), f"case {k}: {h}x{w} density {dens} threshold {mp}: {int((got != want).sum())} pixels differ"
         assert counts.tolist() == [[int((want == c).sum()) for c in range(3)]]
+
+
+def test_predict_labels_with_small_zones(model):
+    """models.py:269-276 in one call: argmax, remove_small_zones, then the optional 2 -> 1 remap."""
+    x = torch.from_numpy(synth.make_input(70, 256, 384))[None].to(DEV)
+    raw, _ = model.predict_labels(x, labels_dtype=torch.uint8)
+    want = remove_small_zones(raw.cpu().numpy())
+    got, counts = model.predict_labels(x, labels_dtype=torch.uint8, small_zones=True)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    want_x = want.copy(); want_x[want_x == 2] = 1
+    got_x, counts_x = model.predict_labels(x, exclude_nodes=True, small_zones=True)
+    assert got_x.dtype == torch.int64
+    np.testing.assert_array_equal(got_x.cpu().numpy(), want_x)
+    assert counts_x.tolist() == [[int((want_x == c).sum()) for c in range(3)]]
