@@ -121,6 +121,15 @@ int nbc_destroy(nbc_ctx* ctx);
 int nbc_attach_weights(nbc_ctx* ctx, const void* dev_blob, size_t bytes, int precision);
 /* Convenience: pack on the host, allocate device memory owned by the context, upload. */
 int nbc_load_weights(nbc_ctx* ctx, const nbc_tensor* tensors, int n, int precision);
+/* Multi-GPU start-up (the reference has no counterpart: it is single-device,
+ * predict.py:66-70): RCCL broadcast of the packed weight blob from rank `root` of `rccl_comm` (an
+ * ncclComm_t of the host process, one rank per GPU) on `hip_stream`.  The root must have weights of
+ * `precision` attached (nbc_load_weights / nbc_attach_weights: it alone read the checkpoint,
+ * predict.py:57); every other rank allocates a blob the context owns, receives into it and attaches
+ * it.  The RCCL entry points are looked up in the host process at call time (the library links
+ * libamdhip64 only); NBC_ERR_STATE when the process holds no RCCL.  The blob is valid once the stream
+ * has been synchronised. */
+int nbc_bcast_weights(nbc_ctx* ctx, void* rccl_comm, int root, int precision, void* hip_stream);
 /* mean/std used for NBC_IN_U8_NHWC input; defaults are models.py:208-209. */
 int nbc_set_normalization(nbc_ctx* ctx, const float mean[3], const float std[3]);
 /* Pre-size the workspace for an (N,H,W) so that the first nbc_forward does not allocate. */
@@ -155,7 +164,7 @@ int nbc_upsample_argmax(nbc_ctx* ctx, const float* logits_lowres_dev, int N, int
  * class 0 become class 1, pixels that joined it become class 0.  The reference uses 150 pixels.
  * labels_dev: uint8 or int64 [N,H,W] (labels_dtype NBC_LABEL_U8 / NBC_LABEL_I64).  exclude_nodes
  * applies the 2 -> 1 remap of models.py:273-276 afterwards; counts_dev (nullable, int64 [N,3]) receives
- * the pixels per class of the result (the counting of models.py:324-331).  N <= 85. */
+ * the pixels per class of the result (the counting of models.py:324-331).  N <= 65535. */
 int nbc_remove_small_zones(nbc_ctx* ctx, void* labels_dev, int labels_dtype, int N, int H, int W, int min_pixels,
                            int exclude_nodes, int64_t* counts_dev, void* hip_stream);
 
@@ -178,12 +187,16 @@ int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
  * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the
  * current (N,H,W) plan (`reps` launches each, HIP events) and keeps the fastest.  Results do not
  * depend on the tile (same K order, one accumulator per output), only speed does.  The choice is
- * part of the plan and is dropped when the plan is rebuilt for another (N,H,W).
+ * part of the plan; the context keeps the plans (and choices) of the last 64 shapes it has seen, so a
+ * folder of height-trimmed images tunes each distinct (N,H,W) once.
  * nbc_get_plan_tiles copies the tile id of each conv launch of the plan; returns their number. */
 int nbc_autotune(nbc_ctx* ctx, const void* x_dev, int x_dtype, int N, int H, int W, int reps, int objective,
                  void* hip_stream);   /* objective 0: time of the launch alone; 1: time x fraction of the 256
                                          CUs it occupies (forwards overlapped on several streams) */
 int nbc_get_plan_tiles(nbc_ctx* ctx, int32_t* tiles, int capacity);
+/* Install a tile choice (one id per conv launch of the current plan, as nbc_get_plan_tiles returns them),
+ * e.g. one measured in an earlier process: NBC_ERR_INVALID when the count or a tile does not fit. */
+int nbc_set_plan_tiles(nbc_ctx* ctx, const int32_t* tiles, int n);
 
 /* ---- debugging / measurement ----------------------------------------------------------- */
 /* Copy the activation written by conv unit `name` during the last forward to `dst_host` as

@@ -20,6 +20,8 @@
 // 64 x BN/2 as 2 x (BN/64) MFMA tiles of 32x32.  LDS: two stages of (128 + BN) rows x 128 B,
 // XOR-swizzled in 16-byte chunks so that the ds_read_b128 fragment reads are conflict free;
 // global -> register -> LDS staging with the next K-step's loads in flight during the MFMAs.
+#include <atomic>
+
 #include "nbc_kernels.hpp"
 
 namespace nbc {
@@ -272,14 +274,14 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
 template <int PREC, int BN, bool STEM>
 hipError_t launch_one(const ConvArgs& a, hipStream_t s) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  static unsigned long long attr_done = 0;     // bit d: attribute set on device d
+  static std::atomic<unsigned long long> attr_done{0};     // bit d: attribute set on device d
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
-  if (!((attr_done >> dev) & 1ull)) {
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {   // setting it twice from two threads is harmless
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<PREC, BN, STEM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    attr_done |= 1ull << dev;
+    attr_done.fetch_or(1ull << dev, std::memory_order_release);
   }
   const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
   hipLaunchKernelGGL((conv_igemm_kernel<PREC, BN, STEM>), dim3(tiles), dim3(THREADS), smem, s, a);

@@ -22,6 +22,8 @@
 // ends up holding one pixel (column) and groups of four consecutive output channels (rows).
 #include <cstdlib>
 
+#include <atomic>
+
 #include "nbc_kernels.hpp"
 
 namespace nbc {
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   // tail rows point at the zero page and do not advance.
   const unsigned char* a_ptr[A_PASSES];
   int a_inc[A_PASSES];
-  auto set_tap = [&](int kh, int kw) {
+  auto set_tap = [&](int kh, int kw) __attribute__((always_inline)) {
     const int dy = kh * p.dil, dx = kw * p.dil;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   if constexpr (!STEM) set_tap(0, 0);
 
   // DMA d (0..L-1: activation passes first, then weight passes) of K-step t into ring slot `stage`.
-  auto issue_one = [&](int d, int t, unsigned sa) {
+  auto issue_one = [&](int d, int t, unsigned sa) __attribute__((always_inline)) {
     if (d < A_PASSES) {
       const int i = d;
       if constexpr (!STEM) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   };
   // The L DMAs of a K-step are issued in four parts so that the main loop can slot one part behind
   // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
-  auto issue_part = [&](int part, int t, int stage) {
+  auto issue_part = [&](int part, int t, int stage) __attribute__((always_inline)) {
     if constexpr (VAR == 4 || VAR == 7) return;      // timing-only ablations: no refill DMAs in the loop
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
       }
     }
   };
-  auto issue_step = [&](int t, int stage) {
+  auto issue_step = [&](int t, int stage) __attribute__((always_inline)) {
 #pragma unroll
     for (int part = 0; part < 4; ++part) issue_part(part, t, stage);
   };
@@ -263,7 +265,15 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   constexpr bool M16 = (PREC == 1 && (VAR == 0 || VAR == 4));
   constexpr int MT16 = 2 * MT, NT16 = 2 * NT;
   const int r16 = lane & 15, q16 = lane >> 4;
+  // f32 (parity mode) sums in two levels: the 32 products of a K-step go through the MFMA's own fma chain
+  // into accI, starting from zero, and accI is added to acc once per K-step (v_add_f32).  The longest
+  // rounding chain is then T + 32 terms instead of 32*T (T up to 576): measured against a float64
+  // evaluation the logit error falls about fourfold, to the level of the CPU reference's own blocked
+  // summation.  Every tile shape does exactly this, so results stay independent of the tile.
+  constexpr bool F32 = (PREC == 0);
+  constexpr bool PREFETCH = F32 && S >= 3;         // see the f32 pipeline below
   f32x16 acc[M16 ? 1 : NT][M16 ? 1 : MT];
+  f32x16 accI[F32 ? NT : 1][F32 ? MT : 1];
   f32x4 acc16[M16 ? NT16 : 1][M16 ? MT16 : 1];
   if constexpr (M16) {
 #pragma unroll
@@ -280,6 +290,106 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][i][e] = 0.f;
   }
+
+#ifdef NBC_STAMPS
+  unsigned long long st_vm = 0, st_bar = 0;         // diagnostic build: cycles each wave spends in the two waits
+#endif
+  // ---- f32 K-step (64 * MT*NT/4 MFMAs of 64 cycles each per wave; two waves share a SIMD's matrix pipe).
+  // With three or more ring slots (PREFETCH) the ONE barrier of a K-step sits in its middle:
+  //   * ks 0,1 run on fragments that were read before the barrier (the first ones at the end of the
+  //     previous step), so no wave ever waits for an LDS round trip with the matrix pipe empty -- with the
+  //     barrier at the top of the step and the first fragments read behind it the head conv kept the pipe
+  //     busy for 0.91 of the K loop (2.37 GHz: 140 of 157 TF);
+  //   * in front of the barrier every wave has waited for its DMAs of step t+1 (issued a whole step
+  //     earlier), behind it slot t+1 is visible to all (its first fragments are read during ks 3) and slot
+  //     t-1 is free: its refill (step t+S-1) is issued in parts between the MFMAs of ks 2 or ks 3;
+  //   * a wave that reaches the barrier first leaves the pipe to its SIMD partner's MFMAs.
+  // Two-slot tiles keep the barrier at the top of the step (`compute`'s caller) and read their first
+  // fragments behind it.
+  uint4 fpf[F32 ? 2 : 1][F32 ? MT : 1], fwf[F32 ? 2 : 1][F32 ? NT : 1];
+  auto load_frags32 = [&](int stage, int ks, uint4 (&pfr)[F32 ? MT : 1], uint4 (&wfr)[F32 ? NT : 1]) __attribute__((always_inline)) {
+    if constexpr (F32) {
+      const unsigned char* sa = smem + stage * STAGE_BYTES;
+      const unsigned char* sb = sa + A_BYTES;
+      const int chunk = 2 * ks + h;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        pfr[i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * MT + i) * 32 + r, chunk));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * NT + j) * 32 + r, chunk));
+    }
+  };
+  // Two-level sum: accI collects FLUSH K-steps (32 * FLUSH products per output) through the MFMA's own fma
+  // chain; a step whose index is a multiple of FLUSH first adds accI to acc and clears it (128 VALU
+  // instructions per wave, behind a wave-uniform branch).  Every non-MFMA instruction costs the matrix pipe
+  // about its own issue time (tools/mfma_f32_probe.hip: 64 adds in every K-step cost 6 %), hence not every
+  // step; FLUSH = 8 also gives the smaller rounding error for the long chains (sqrt(256) + sqrt(T/8)
+  // against sqrt(32) + sqrt(T)).
+  constexpr int NTILES = NT * MT;
+  constexpr int FLUSH = 8;
+  // An LDS-DMA costs its wave 60-185 cycles of issue (MI355X_MICROARCH.md): the two waves of a SIMD (w and
+  // w + half the block) issue their shares of the refill in different quarters of the step (ks 2 / ks 3).
+  const bool late = WM * WN >= 8 && wave >= WM * WN / 2;
+  if constexpr (F32) {
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accI[n / MT][n % MT][e] = 0.f;
+  }
+  auto compute32 = [&](bool flush, int stage, bool more, bool all_issued, int next_stage, bool do_issue, int t_issue, int issue_stage)
+      __attribute__((always_inline)) {
+    if constexpr (F32) {
+      if constexpr (!PREFETCH) load_frags32(stage, 0, fpf[0], fwf[0]);
+      if (flush) {                                           // wave-uniform: every FLUSH-th step
+#pragma unroll
+        for (int n = 0; n < NTILES; ++n) {
+          acc[n / MT][n % MT] += accI[n / MT][n % MT];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) accI[n / MT][n % MT][e] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (PREFETCH && ks == 2 && more) {                   // wave-uniform
+#ifdef NBC_STAMPS
+          const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+          if (S > 3 && all_issued) wait_vmcnt<(S - 3) * L>();      // step t+1 has landed (own share)
+          else wait_vmcnt<0>();
+#ifdef NBC_STAMPS
+          const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+          __builtin_amdgcn_s_barrier();
+#ifdef NBC_STAMPS
+          st_vm += st1 - st0; st_bar += __builtin_amdgcn_s_memtime() - st1;
+#endif
+        }
+        if (ks + 1 < 4) load_frags32(stage, ks + 1, fpf[(ks + 1) & 1], fwf[(ks + 1) & 1]);
+        else if (PREFETCH && more) load_frags32(next_stage, 0, fpf[0], fwf[0]);
+#pragma unroll
+        for (int n = 0; n < NTILES; ++n) {
+          const int j = n / MT, i = n % MT;
+          const float4 wv = __builtin_bit_cast(float4, fwf[ks & 1][j]);
+          const float4 pv = __builtin_bit_cast(float4, fpf[ks & 1][i]);
+          accI[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, pv.x, accI[j][i], 0, 0, 0);
+          accI[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, pv.y, accI[j][i], 0, 0, 0);
+          accI[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, pv.z, accI[j][i], 0, 0, 0);
+          accI[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, accI[j][i], 0, 0, 0);
+          if (PREFETCH && ks >= 2 && do_issue && (ks == 3) == late) {   // wave-uniform: refill parts behind this tile's MFMAs
+#pragma unroll
+            for (int part = 0; part < 4; ++part)
+              if (part * NTILES / 4 == n) issue_part(part, t_issue, issue_stage);
+          }
+        }
+      }
+    }
+  };
+  // one K-step of the f32 kernel
+  auto step32 = [&](int t, int stage, bool more, bool all_issued, int next_stage, bool do_issue, int t_issue, int issue_stage)
+      __attribute__((always_inline)) {
+    compute32(t > 0 && (t & (FLUSH - 1)) == 0, stage, more, all_issued, next_stage, do_issue, t_issue, issue_stage);
+  };
 
   // Fragments are double-buffered in registers: the ds_read_b128 of chunk pair ks+1 are issued
   // before the MFMAs of chunk pair ks, so LDS latency hides under the matrix pipe.
@@ -361,18 +471,9 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          if constexpr (PREC == 1) {
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                __builtin_bit_cast(bf16x8, wf[ks & 1][j]), __builtin_bit_cast(bf16x8, pf[ks & 1][i]),
-                acc[j][i], 0, 0, 0);
-          } else {
-            const float4 wv = __builtin_bit_cast(float4, wf[ks & 1][j]);
-            const float4 pv = __builtin_bit_cast(float4, pf[ks & 1][i]);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, pv.x, acc[j][i], 0, 0, 0);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, pv.y, acc[j][i], 0, 0, 0);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, pv.z, acc[j][i], 0, 0, 0);
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, pv.w, acc[j][i], 0, 0, 0);
-          }
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, wf[ks & 1][j]), __builtin_bit_cast(bf16x8, pf[ks & 1][i]),
+              acc[j][i], 0, 0, 0);
         }
       if (do_issue) issue_part(ks, t_issue, issue_stage);   // wave-uniform branch
     }
@@ -432,9 +533,24 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   for (int s = 0; s < S - 1; ++s)
     if (s < T) issue_step(s, s);
   NBC_STAMP(1);                                     // prologue DMAs issued
+  if constexpr (PREFETCH) {
+    // f32 pipeline, S >= 3 slots (see compute32): steps 0 .. S-2 are in flight; step 0 must be visible
+    // before its first fragments are read, everything later is handled by the mid-step barriers.
+    if (S - 2 < T) wait_vmcnt<(S - 2) * L>();                  // step 0 has landed (own share)
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags32(0, 0, fpf[0], fwf[0]);
+    NBC_STAMP(2); NBC_STAMP_CLK(11);
+    for (int t = 0; t < T - 1; ++t)
+      step32(t, t % S, true, t + S - 2 < T, (t + 1) % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
+    NBC_STAMP(3);
+    NBC_STAMP_CLK(12);
 #ifdef NBC_STAMPS
-  unsigned long long st_vm = 0, st_bar = 0;         // diagnostic build: cycles each wave spends in the two waits
+    if (p.stamps && lane == 0) { p.stamps[(size_t)blockIdx.x * 64 + 16 + wave] = st_vm; p.stamps[(size_t)blockIdx.x * 64 + 32 + wave] = st_bar; }
 #endif
+    prefetch_identity();                                         // no DMA is outstanding any more
+    step32(T - 1, (T - 1) % S, false, false, 0, false, 0, 0);
+  } else {
   for (int t = 0; t < T - 1; ++t) {
     // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
 #ifdef NBC_STAMPS
@@ -455,7 +571,8 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
     // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
     if constexpr (S == 2) {
       if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
-      compute(t % S, false, 0, 0);
+      if constexpr (F32) step32(t, t % S, false, false, 0, false, 0, 0);
+      else compute(t % S, false, 0, 0);
     } else {
       compute(t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
     }
@@ -470,7 +587,14 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   if (p.stamps && lane == 0) { p.stamps[(size_t)blockIdx.x * 64 + 16 + wave] = st_vm; p.stamps[(size_t)blockIdx.x * 64 + 32 + wave] = st_bar; }
 #endif
   prefetch_identity();
-  compute((T - 1) % S, false, 0, 0);
+  if constexpr (F32) step32(T - 1, (T - 1) % S, false, false, 0, false, 0, 0);
+  else compute((T - 1) % S, false, 0, 0);
+  }
+
+  if constexpr (F32) {                                // the last chain joins the running sum
+#pragma unroll
+    for (int n = 0; n < NTILES; ++n) acc[n / MT][n % MT] += accI[n / MT][n % MT];
+  }
 
   // ---- epilogue.
   // The accumulators hold, per lane, one pixel and groups of four channels: stored as they stand,
@@ -607,15 +731,15 @@ template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int smem = ring_bytes(PREC, WM, WN, MT, NT, S) + 2048;     // ring (or scratch) + scale/shift table
-  static unsigned long long attr_done = 0;     // bit d: attribute set on device d (one context per device)
+  static std::atomic<unsigned long long> attr_done{0};     // bit d: attribute set on device d (one context per device)
   auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
-  if (!((attr_done >> dev) & 1ull)) {
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {   // setting it twice from two threads is harmless
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    attr_done |= 1ull << dev;
+    attr_done.fetch_or(1ull << dev, std::memory_order_release);
   }
   if (a.Co % BN != 0) return hipErrorInvalidValue;
   const int tiles = ((a.M + BM - 1) / BM) * (a.Co / BN);
@@ -643,14 +767,16 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);
     case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);
     case 2: return launch_cfg<PREC, 4, 2, 2, 2, 3, STEM, VAR>(a, s);
-    case 3: return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, VAR>(a, s);
+    case 3:
+      if constexpr (PREC == 0) return hipErrorInvalidValue;   // 2 x 128 accumulator registers: no f32 form
+      else return launch_cfg<PREC, 2, 4, 4, 2, 2, STEM, VAR>(a, s);
     case 4: return launch_cfg<PREC, 2, 2, 2, 2, 4, STEM, VAR>(a, s);
     case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, VAR>(a, s);
     case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, VAR>(a, s);
     case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM, VAR>(a, s);
     case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM, VAR>(a, s);
-    case 9: return launch_cfg<PREC, 4, 2, 1, 2, 2, STEM, VAR>(a, s);
-    case 10: return launch_cfg<PREC, 4, 2, 1, 1, 2, STEM, VAR>(a, s);
+    case 9: return launch_cfg<PREC, 4, 2, 1, 2, PREC == 0 ? 3 : 2, STEM, VAR>(a, s);    // f32: three slots (96 KiB, fragment prefetch)
+    case 10: return launch_cfg<PREC, 4, 2, 1, 1, PREC == 0 ? 3 : 2, STEM, VAR>(a, s);   // f32: 72 KiB, two blocks per CU
     case 11: return launch_cfg<PREC, 4, 4, 2, 1, 2, STEM, VAR>(a, s);
     default: return hipErrorInvalidValue;
   }
@@ -667,12 +793,19 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 // Default tile (before nbc_autotune measures): the largest tile that still yields at least one
 // tile per CU (256); when no shape does, the one with the most tiles.  Bigger tiles move fewer
 // L2->LDS bytes per FLOP.
-int choose_conv_tile(int M, int Co) {
+// Whether tile id `tile` exists for this precision and divides the layer's output channels.
+bool conv_tile_ok(int precision, int tile, int Co) {
+  if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
+  if (precision == 0 && tile == 3) return false;            // the f32 kernel keeps two accumulator sets
+  return Co % kTileCols[tile] == 0;
+}
+
+int choose_conv_tile(int M, int Co, int precision) {
   const int order[4] = {3, 2, 1, 0};
   int best = -1, best_tiles = -1;
   for (int k = 0; k < 4; ++k) {
     const int t = order[k];
-    if (Co % conv_tile_cols(t) != 0) continue;
+    if (!conv_tile_ok(precision, t, Co)) continue;
     const int tiles = ((M + conv_tile_rows(t) - 1) / conv_tile_rows(t)) * (Co / conv_tile_cols(t));
     if (tiles >= 256) return t;
     if (tiles > best_tiles) { best = t; best_tiles = tiles; }
@@ -688,8 +821,8 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   } else {
     if ((a.Ci * eb) % 128 != 0 || a.ksteps != a.KH * a.KW * (a.Ci * eb / 128)) return hipErrorInvalidValue;
   }
-  if (tile < 0) tile = choose_conv_tile(a.M, a.Co);
-  if (tile < 0 || tile >= CONV_TILE_COUNT || a.Co % conv_tile_cols(tile) != 0) return hipErrorInvalidValue;
+  if (tile < 0) tile = choose_conv_tile(a.M, a.Co, precision);
+  if (!conv_tile_ok(precision, tile, a.Co)) return hipErrorInvalidValue;
   // NBC_CONV_ABLATE=1 (no MFMA) / 2 (no refill DMA): timing-only builds of the bf16 256x256 and
   // 128x256 tiles, results are garbage.  Never set outside an experiment.
   static const int ablate = [] { const char* e = getenv("NBC_CONV_ABLATE"); return e ? atoi(e) : 0; }();

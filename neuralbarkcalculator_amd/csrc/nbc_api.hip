@@ -2,6 +2,7 @@
 //
 // nbc_forward replaces, at the C ABI, `outputs = self.model(batch[0].to(self.device))` followed
 // by `torch.argmax(outputs, dim=1)` (/root/reference/src/bark_calculator/models.py:269-270).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -57,7 +58,8 @@ struct nbc_ctx {
   PackedLayout layout;
   float mean[3] = {0.7399f, 0.6139f, 0.4401f};   // models.py:208
   float stdv[3] = {0.1068f, 0.1272f, 0.1271f};   // models.py:209
-  Plan plan;
+  Plan plan;                                // plan of the current (N,H,W)
+  std::vector<Plan> plan_cache;             // plans (with their tuned tiles) of the other shapes seen, oldest first
   std::vector<void*> bufs;
   std::vector<size_t> buf_cap;
   float* lowres = nullptr;
@@ -80,6 +82,24 @@ struct nbc_ctx {
 };
 
 namespace {
+
+constexpr size_t kPlanCacheEntries = 64;
+
+bool same_shape(const Plan& p, int N, int H, int W, int precision, bool keep) {
+  return p.N == N && p.H == H && p.W == W && p.precision == precision && p.keep == keep;
+}
+
+// Park the current plan (folders of height-trimmed images alternate between a few shapes: each keeps
+// its launch list and its measured tile choice instead of being rebuilt on every change).
+void stash_plan(nbc_ctx* c) {
+  Plan& cur = c->plan;
+  if (cur.N == 0) return;
+  for (Plan& p : c->plan_cache)
+    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep)) { p = cur; cur = Plan(); return; }
+  if (c->plan_cache.size() >= kPlanCacheEntries) c->plan_cache.erase(c->plan_cache.begin());
+  c->plan_cache.push_back(cur);
+  cur = Plan();
+}
 
 // Build the launch list for an (N,H,W).  Activation buffers are recycled through a small pool
 // unless `keep` asks for one buffer per op (layer-by-layer parity tests).
@@ -122,7 +142,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
     o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
-    o.tile = choose_conv_tile(N * Ho * Wo, u.cout);
+    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, c->precision);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
     o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +
@@ -193,7 +213,14 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
   }
   (void)L;
 
-  // (re)allocate buffers
+  c->plan = P;
+  return NBC_OK;
+}
+
+// Workspace of the current plan: buffers only ever grow, so a plan taken back from the cache finds
+// them large enough unless a later, smaller-indexed plan never needed that slot.
+int ensure_buffers(nbc_ctx* c) {
+  const Plan& P = c->plan;
   if (c->bufs.size() < P.buf_bytes.size()) { c->bufs.resize(P.buf_bytes.size(), nullptr); c->buf_cap.resize(P.buf_bytes.size(), 0); }
   for (size_t i = 0; i < P.buf_bytes.size(); ++i) {
     if (c->buf_cap[i] < P.buf_bytes[i]) {
@@ -204,7 +231,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
       c->buf_cap[i] = P.buf_bytes[i];
     }
   }
-  const size_t lr = (size_t)N * kNumClasses * P.h * P.w * sizeof(float);
+  const size_t lr = (size_t)P.N * kNumClasses * P.h * P.w * sizeof(float);
   if (c->lowres_cap < lr) {
     if (c->lowres) NBC_HIP(hipFree(c->lowres));
     c->lowres = nullptr; c->lowres_cap = 0;
@@ -213,7 +240,6 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
   }
   c->act_of.clear();
   for (size_t i = 0; i < P.ops.size(); ++i) c->act_of[P.ops[i].name] = (int)i;
-  c->plan = P;
   return NBC_OK;
 }
 
@@ -313,7 +339,7 @@ int nbc_attach_weights(nbc_ctx* c, const void* dev_blob, size_t bytes, int preci
   if (c->owned_weights && c->owned_weights != dev_blob) { (void)hipFree(c->owned_weights); c->owned_weights = nullptr; }
   c->weights = static_cast<const unsigned char*>(dev_blob);
   c->layout = L;
-  if (c->precision != precision) c->plan = Plan();   // element size changed: re-plan
+  if (c->precision != precision) stash_plan(c);      // element size changed: another plan
   c->precision = precision;
   return NBC_OK;
 }
@@ -338,6 +364,59 @@ int nbc_load_weights(nbc_ctx* c, const nbc_tensor* tensors, int n, int precision
   return NBC_OK;
 }
 
+// RCCL is resolved at call time from the host process (the library itself links libamdhip64 only):
+// whatever librccl the host has loaded -- torch's own, or /opt/rocm's -- is the one whose communicator
+// the caller hands in.
+namespace {
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*nccl_rank_fn)(void*, int*);
+void* rccl_symbol(const char* name) {
+  void* f = dlsym(RTLD_DEFAULT, name);
+  if (f) return f;
+  static void* handle = [] {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    return h ? h : dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  }();
+  return handle ? dlsym(handle, name) : nullptr;
+}
+}  // namespace
+
+int nbc_bcast_weights(nbc_ctx* c, void* rccl_comm, int root, int precision, void* hip_stream) {
+  if (!c || !rccl_comm) return set_error(NBC_ERR_INVALID, "nbc_bcast_weights: null argument");
+  const size_t bytes = nbc_packed_weights_bytes(precision);
+  if (bytes == 0) return set_error(NBC_ERR_INVALID, "nbc_bcast_weights: unknown precision");
+  auto bcast = reinterpret_cast<nccl_bcast_fn>(rccl_symbol("ncclBroadcast"));
+  auto user_rank = reinterpret_cast<nccl_rank_fn>(rccl_symbol("ncclCommUserRank"));
+  if (!bcast || !user_rank) return set_error(NBC_ERR_STATE, "nbc_bcast_weights: no RCCL (librccl.so) in this process");
+  int rank = -1;
+  if (user_rank(rccl_comm, &rank) != 0) return set_error(NBC_ERR_INVALID, "nbc_bcast_weights: ncclCommUserRank failed (bad communicator?)");
+  NBC_HIP(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  void* blob = nullptr;
+  bool fresh = false;
+  if (rank == root) {
+    if (!c->weights || c->precision != precision)
+      return set_error(NBC_ERR_STATE, "nbc_bcast_weights: the root rank has no weights of this precision attached");
+    blob = const_cast<unsigned char*>(c->weights);
+  } else {
+    NBC_HIP(hipMalloc(&blob, bytes));
+    fresh = true;
+  }
+  const int rc = bcast(blob, blob, bytes, /*ncclUint8*/ 1, root, rccl_comm, s);
+  if (rc != 0) {
+    if (fresh) (void)hipFree(blob);
+    return set_error(NBC_ERR_HIP, "nbc_bcast_weights: ncclBroadcast returned " + std::to_string(rc));
+  }
+  if (fresh) {
+    if (c->owned_weights) (void)hipFree(c->owned_weights);     // synchronises: nothing of the old blob is in flight
+    c->owned_weights = nullptr;
+    const int arc = nbc_attach_weights(c, blob, bytes, precision);
+    if (arc != NBC_OK) { (void)hipFree(blob); return arc; }
+    c->owned_weights = blob;
+  }
+  return NBC_OK;
+}
+
 int nbc_set_normalization(nbc_ctx* c, const float mean[3], const float stdv[3]) {
   if (!c || !mean || !stdv) return set_error(NBC_ERR_INVALID, "nbc_set_normalization: null argument");
   for (int i = 0; i < 3; ++i) { c->mean[i] = mean[i]; c->stdv[i] = stdv[i]; }
@@ -355,7 +434,7 @@ int nbc_set_conv_impl(nbc_ctx* c, int impl, int tile) {
 
 int nbc_set_keep_activations(nbc_ctx* c, int on) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
-  if (c->keep != (on != 0)) c->plan = Plan();
+  if (c->keep != (on != 0)) stash_plan(c);
   c->keep = on != 0;
   return NBC_OK;
 }
@@ -371,9 +450,18 @@ int nbc_reserve(nbc_ctx* c, int N, int H, int W) {
   if (c->precision < 0) return set_error(NBC_ERR_STATE, "nbc_reserve: no weights attached");
   if (N < 1 || H < 8 || W < 8) return set_error(NBC_ERR_INVALID, "nbc_reserve: need N>=1, H>=8, W>=8");
   NBC_HIP(hipSetDevice(c->device));
-  const Plan& P = c->plan;
-  if (P.N == N && P.H == H && P.W == W && P.precision == c->precision && P.keep == c->keep) return NBC_OK;
-  return build_plan(c, N, H, W);
+  if (same_shape(c->plan, N, H, W, c->precision, c->keep)) return NBC_OK;
+  stash_plan(c);
+  bool found = false;
+  for (const Plan& p : c->plan_cache)
+    if (same_shape(p, N, H, W, c->precision, c->keep)) { c->plan = p; found = true; break; }
+  if (!found) {
+    int rc = build_plan(c, N, H, W);
+    if (rc != NBC_OK) return rc;
+  }
+  int rc = ensure_buffers(c);
+  if (rc != NBC_OK) c->plan = Plan();
+  return rc;
 }
 
 int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
@@ -419,7 +507,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         break;
       case OP_CONV: {
         int tile = c->conv_tile;
-        if (tile < 0 || o.Co % conv_tile_cols(tile) != 0) tile = o.tile;   // override does not fit: planned tile
+        if (!conv_tile_ok(prec, tile, o.Co)) tile = o.tile;   // no override, or it does not fit: planned tile
         rc = launch_conv_op(c, o, N, c->conv_impl, tile, s, &e);
         if (rc != NBC_OK) return rc;
         break;
@@ -505,7 +593,7 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
     float best_ms = 1e30f;
     int best = o.tile;
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
-      if (o.Co % conv_tile_cols(tile) != 0) continue;
+      if (!conv_tile_ok(c->precision, tile, o.Co)) continue;
       hipError_t e = hipSuccess;
       rc = launch_conv_op(c, o, N, 1, tile, s, &e);                       // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
@@ -538,6 +626,25 @@ int nbc_get_plan_tiles(nbc_ctx* c, int32_t* tiles, int capacity) {
   return n;
 }
 
+int nbc_set_plan_tiles(nbc_ctx* c, const int32_t* tiles, int n) {
+  if (!c || !tiles) return set_error(NBC_ERR_INVALID, "nbc_set_plan_tiles: null argument");
+  int convs = 0;
+  for (const Op& o : c->plan.ops) convs += o.kind == OP_CONV;
+  if (convs == 0) return set_error(NBC_ERR_STATE, "nbc_set_plan_tiles: no plan (nbc_reserve first)");
+  if (n != convs) return set_error(NBC_ERR_INVALID, "nbc_set_plan_tiles: the plan has " + std::to_string(convs) + " convolutions");
+  int k = 0;
+  for (const Op& o : c->plan.ops) {
+    if (o.kind != OP_CONV) continue;
+    const int t = tiles[k++];
+    if (!conv_tile_ok(c->precision, t, o.Co))
+      return set_error(NBC_ERR_INVALID, "nbc_set_plan_tiles: tile " + std::to_string(t) + " does not fit " + o.name);
+  }
+  k = 0;
+  for (Op& o : c->plan.ops)
+    if (o.kind == OP_CONV) o.tile = tiles[k++];
+  return NBC_OK;
+}
+
 int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, int H, int W,
                         float* logits_full_dev, void* labels_dev, int labels_dtype,
                         int64_t* counts_dev, int exclude_nodes, void* hip_stream) {
@@ -556,7 +663,7 @@ int nbc_upsample_argmax(nbc_ctx* c, const float* lowres, int N, int h, int w, in
 int nbc_remove_small_zones(nbc_ctx* c, void* labels_dev, int labels_dtype, int N, int H, int W, int min_pixels,
                            int exclude_nodes, int64_t* counts_dev, void* hip_stream) {
   if (!c || !labels_dev) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: null argument");
-  if (N < 1 || N > 85 || H < 1 || W < 1 || min_pixels < 0) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: bad shape");
+  if (N < 1 || N > 65535 || H < 1 || W < 1 || min_pixels < 0) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: bad shape");
   if (labels_dtype != NBC_LABEL_U8 && labels_dtype != NBC_LABEL_I64) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: bad labels_dtype");
   NBC_HIP(hipSetDevice(c->device));
   const size_t px = (size_t)N * H * W;

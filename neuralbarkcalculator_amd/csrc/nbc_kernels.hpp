@@ -39,7 +39,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
 constexpr int CONV_TILE_COUNT = 12;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
-int choose_conv_tile(int M, int Co);
+bool conv_tile_ok(int precision, int tile, int Co);   // the tile exists for the precision and divides Co
+int choose_conv_tile(int M, int Co, int precision);
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
 
 // float32 NCHW [N,3,H,W] -> NHWC elements padded to 16 bytes per pixel.

@@ -567,8 +567,11 @@ hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int 
 hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, int out_h, int out_w, unsigned* minmax,
                                   hipStream_t s) {
   if (H < 1 || W < 1 || out_h < 1 || out_w < 1 || out_h > 65535) return hipErrorInvalidValue;
-  const unsigned init[2] = {255u, 0u};
-  hipError_t e = hipMemcpyAsync(minmax, init, sizeof(init), hipMemcpyHostToDevice, s);
+  // min starts at 255 (0xFF in every byte of the word's low byte is enough: values are <= 255), max at 0:
+  // two device-side fills, no host source buffer that would have to outlive the call
+  hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(minmax), 255, 1, s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(minmax + 1), 0, 1, s);
   if (e != hipSuccess) return e;
   const size_t n = (size_t)H * W * 3;
   hipLaunchKernelGGL(minmax_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, n, minmax);

@@ -233,8 +233,8 @@ __global__ void apply_kernel(LabelT* __restrict__ labels, unsigned char* __restr
 }
 
 __global__ void finish_counts_kernel(unsigned long long* counts, int N, unsigned long long pixels) {
-  const int i = threadIdx.x;
-  if (i < N) counts[i * 3] = pixels - counts[i * 3 + 1] - counts[i * 3 + 2];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+    counts[(size_t)i * 3] = pixels - counts[(size_t)i * 3 + 1] - counts[(size_t)i * 3 + 2];
 }
 
 template <typename LabelT>
@@ -254,7 +254,7 @@ hipError_t run(LabelT* labels, int N, int H, int W, int min_pixels, int exclude_
     hipLaunchKernelGGL(apply_kernel<LabelT>, rows, dim3(256), 0, s, labels, bg, parent, size, H, W, min_pixels, phase,
                        exclude_nodes, counts);
   }
-  if (counts) hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(256), 0, s, counts, N, (unsigned long long)H * W);
+  if (counts) hipLaunchKernelGGL(finish_counts_kernel, dim3((N + 255) / 256), dim3(256), 0, s, counts, N, (unsigned long long)H * W);
   return hipGetLastError();
 }
 
@@ -262,7 +262,7 @@ hipError_t run(LabelT* labels, int N, int H, int W, int min_pixels, int exclude_
 
 hipError_t launch_remove_small_zones(void* labels, int labels_i64, int N, int H, int W, int min_pixels, int exclude_nodes,
                                      unsigned char* bg, int* parent, int* size, unsigned long long* counts, hipStream_t s) {
-  if (N < 1 || N > 85 || H < 1 || W < 1 || H > 65535 || (long long)H * W > 0x7fffffffLL) return hipErrorInvalidValue;
+  if (N < 1 || N > 65535 || H < 1 || W < 1 || H > 65535 || (long long)H * W > 0x7fffffffLL) return hipErrorInvalidValue;
   if (labels_i64) return run(static_cast<long long*>(labels), N, H, W, min_pixels, exclude_nodes, bg, parent, size, counts, s);
   return run(static_cast<unsigned char*>(labels), N, H, W, min_pixels, exclude_nodes, bg, parent, size, counts, s);
 }

@@ -308,6 +308,12 @@ class FCNResNet50:
         n = self._lib.nbc_get_plan_tiles(self._require_ctx(), buf, 64)
         return [int(buf[i]) for i in range(min(n, 64))]
 
+    def set_plan_tiles(self, tiles):
+        """Install a per-layer tile choice (as ``plan_tiles`` / ``autotune`` return it) for the current
+        (N,H,W) plan, e.g. one measured by an earlier process."""
+        arr = (C.c_int32 * len(tiles))(*[int(t) for t in tiles])
+        _lib.check(self._lib.nbc_set_plan_tiles(self._require_ctx(), arr, len(tiles)), "nbc_set_plan_tiles")
+
     def set_keep_activations(self, on: bool):
         _lib.check(self._lib.nbc_set_keep_activations(self._require_ctx(), int(on)))
 

@@ -1,0 +1,146 @@
+"""BASELINE.json configs[2] (batch 8, bf16) under test at the full frame size, and the float64
+adjudication of the f32 parity mode's label flips.
+
+Tolerances (written here, used below):
+  * bf16 throughput mode, batch 8 at 1024x1024: logits within LOGIT_RTOL_BF16 of the oracle's logit range per
+    frame, label agreement >= 98 % per frame, every disagreement at an oracle top-2 margin below
+    BF16_MARGIN_BAND of the logit range;
+  * batch 8 == eight batch-1 calls, bit for bit (labels, counts, low-res logits), both modes;
+  * f32 parity mode against the SAME network evaluated in float64 on the CPU (the adjudicator): logits within
+    LOGIT_RTOL_FP32 of the logit range; labels IDENTICAL to the float64 labels wherever the float64 top-2
+    margin exceeds twice the measured f32 logit error; wherever the HIP f32 labels differ from the CPU f32
+    oracle's, the float64 result says which side is right, and the tally is reported (and written to
+    gpurun_out/fp64_adjudication.json when that directory exists).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from neuralbarkcalculator_amd import synth
+from neuralbarkcalculator_amd.model import FCNResNet50
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_RTOL_FP32 = 2e-5
+LOGIT_RTOL_BF16 = 4e-2
+BF16_MARGIN_BAND = 0.10
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu_fp32(built_lib, sd_np):
+    return FCNResNet50("fp32").load_state_dict(sd_np).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def gpu_bf16(built_lib, sd_np):
+    return FCNResNet50("bf16").load_state_dict(sd_np).to(DEV)
+
+
+@pytest.fixture(scope="module")
+def oracle_f64(sd_np):
+    """The oracle's topology with every parameter and activation in float64 (torch CPU): the adjudicator."""
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50
+    m = OracleFCNResNet50()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    return m.double()
+
+
+def frames(idx, h, w):
+    return torch.from_numpy(np.stack([synth.make_input(int(i), h, w) for i in idx]))
+
+
+def test_config2_batch8_bf16_at_1024_vs_oracle(oracle_model, gpu_bf16):
+    """configs[2]: ONE batch of 8 distinct 1024x1024 frames through the bf16 path vs the oracle, frame by frame."""
+    from oracle.fcn_resnet50_oracle import predict_labels
+    idx = list(range(50, 58))
+    x = frames(idx, 1024, 1024)
+    xd = x.to(DEV)
+    gpu_bf16.autotune(xd, objective="latency")             # the tiles bench.py's configs[2] leg runs with
+    labels, counts, lowres = gpu_bf16.predict_labels(xd, labels_dtype=torch.uint8, return_lowres=True)
+    logits = gpu_bf16(xd)
+    torch.cuda.synchronize()
+    assert tuple(labels.shape) == (8, 1024, 1024) and tuple(counts.shape) == (8, 3)
+    assert torch.equal(labels.long(), torch.argmax(logits, 1))
+    assert counts.sum(1).tolist() == [1024 * 1024] * 8
+    worst_agree, worst_err = 1.0, 0.0
+    for b, i in enumerate(idx):
+        labels_ref, counts_ref, logits_ref, lowres_ref = predict_labels(oracle_model, x[b:b + 1])
+        scale = float(logits_ref.abs().max())
+        err = float((logits[b].cpu() - logits_ref[0]).abs().max())
+        assert err <= LOGIT_RTOL_BF16 * scale, (i, err, scale)
+        mism = labels[b].cpu().long() != labels_ref[0]
+        agree = 1.0 - float(mism.float().mean())
+        assert agree >= 0.98, (i, agree)
+        if mism.any():
+            top2 = torch.topk(logits_ref, 2, dim=1).values
+            margin = (top2[:, 0] - top2[:, 1])[0]
+            assert float(margin[mism].max()) <= BF16_MARGIN_BAND * scale, (i, float(margin[mism].max()), scale)
+        assert (counts_ref[0] > 0.02 * 1024 * 1024).all(), counts_ref       # a frame with all three classes
+        worst_agree, worst_err = min(worst_agree, agree), max(worst_err, err / scale)
+    print("configs[2] batch 8 bf16 @1024: worst label agreement %.5f, worst rel. logit error %.4f" % (worst_agree, worst_err))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_batch8_equals_eight_singles_at_1024(gpu_fp32, gpu_bf16, mode):
+    """A frame's result does not depend on the batch it rides in: batch 8 == 8 x batch 1, bit for bit."""
+    model = gpu_fp32 if mode == "fp32" else gpu_bf16
+    x = frames(range(60, 68), 1024, 1024).to(DEV)
+    labels, counts, lowres = model.predict_labels(x, labels_dtype=torch.uint8, return_lowres=True)
+    torch.cuda.synchronize()
+    for b in range(8):
+        l1, c1, r1 = model.predict_labels(x[b:b + 1], labels_dtype=torch.uint8, return_lowres=True)
+        assert torch.equal(r1[0], lowres[b]), f"frame {b}: low-res logits differ ({mode})"
+        assert torch.equal(l1[0], labels[b]) and torch.equal(c1[0], counts[b]), f"frame {b} ({mode})"
+
+
+@pytest.mark.parametrize("name", ["c128", "b2_256", "full1024"])
+def test_fp32_label_flips_adjudicated_by_float64(oracle_model, oracle_f64, gpu_fp32, name):
+    from oracle.fcn_resnet50_oracle import predict_labels
+    g = load_golden(name)
+    h, w = (int(v) for v in g["hw"])
+    x = frames(g["frames"], h, w)
+    lab32, _, log32, _ = predict_labels(oracle_model, x)                 # CPU f32 oracle
+    lab64, _, log64, _ = predict_labels(oracle_f64, x.double())          # float64 adjudicator
+    xd = x.to(DEV)
+    labels, counts = gpu_fp32.predict_labels(xd)
+    logits = gpu_fp32(xd)
+    torch.cuda.synchronize()
+    labels, logits = labels.cpu(), logits.cpu().double()
+    scale = float(log64.abs().max())
+    err_hip = float((logits - log64).abs().max())
+    err_cpu = float((log32.double() - log64).abs().max())
+    assert err_hip <= LOGIT_RTOL_FP32 * scale, (err_hip, scale)
+    top2 = torch.topk(log64, 2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    # (i) outside the tie band the integer labels are the float64 labels
+    clear = margin > 2.0 * err_hip
+    assert torch.equal(labels[clear], lab64[clear]), "an HIP f32 label differs from float64 outside the tie band"
+    # (ii) every pixel where HIP f32 and the CPU f32 oracle disagree: who agrees with float64?
+    flip = labels != lab32
+    n_flip = int(flip.sum())
+    hip_right = int((labels[flip] == lab64[flip]).sum())
+    cpu_right = int((lab32[flip] == lab64[flip]).sum())
+    report = {"case": name, "pixels": int(labels.numel()), "logit_range": scale,
+              "max_abs_logit_err_hip_f32_vs_f64": err_hip, "max_abs_logit_err_cpu_f32_vs_f64": err_cpu,
+              "labels_hip_f32_vs_cpu_f32_oracle_differ": n_flip,
+              "of_those_hip_agrees_with_f64": hip_right, "of_those_cpu_oracle_agrees_with_f64": cpu_right,
+              "labels_hip_f32_vs_f64_differ": int((labels != lab64).sum()),
+              "labels_cpu_f32_vs_f64_differ": int((lab32 != lab64).sum()),
+              "max_f64_margin_at_any_hip_vs_f64_difference": float(margin[labels != lab64].max()) if bool((labels != lab64).any()) else 0.0,
+              "pixels_inside_tie_band_2x_err_hip": int((~clear).sum())}
+    print(json.dumps(report))
+    # a flipped pixel is a tie: with three classes one of the two sides carries the float64 label
+    assert hip_right + cpu_right >= n_flip
+    assert n_flip <= int((~clear).sum())
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        path = os.path.join(out, "fp64_adjudication.json")
+        prev = json.load(open(path)) if os.path.exists(path) else {}
+        prev[name] = report
+        json.dump(prev, open(path, "w"), indent=1)

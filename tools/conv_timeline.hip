@@ -26,13 +26,22 @@ int main(int argc, char** argv) {
   const int Hi = atoi(argv[1]), Wi = atoi(argv[2]), Ci = atoi(argv[3]), Co = atoi(argv[4]);
   const int K = atoi(argv[5]), dil = atoi(argv[6]), res = atoi(argv[7]), tile = atoi(argv[8]);
   if (Hi < 1 || Wi < 1 || Ci % 64 || Co % 64 || (K != 1 && K != 3) || tile < 0 || tile >= nbc::CONV_TILE_COUNT) return 2;
-  const int M = Hi * Wi, ksteps = K * K * Ci * 2 / 128;
-  const size_t xb = (size_t)M * Ci * 2, wb = (size_t)Co * ksteps * 128, yb = (size_t)M * Co * 2;
+  const int prec = argc > 10 ? atoi(argv[10]) : 1;          // 1 = bf16 (default), 0 = f32
+  const int eb = prec == 0 ? 4 : 2;
+  const int M = Hi * Wi, ksteps = K * K * Ci * eb / 128;
+  const size_t xb = (size_t)M * Ci * eb, wb = (size_t)Co * ksteps * 128, yb = (size_t)M * Co * eb;
   std::vector<unsigned short> hx(xb / 2), hw(wb / 2), hr(yb / 2);
   unsigned seed = 12345u;
-  for (auto& v : hx) v = rnd_bf16(seed, 1.f);
-  for (auto& v : hw) v = rnd_bf16(seed, 0.05f);
-  for (auto& v : hr) v = rnd_bf16(seed, 1.f);
+  if (prec == 1) {
+    for (auto& v : hx) v = rnd_bf16(seed, 1.f);
+    for (auto& v : hw) v = rnd_bf16(seed, 0.05f);
+    for (auto& v : hr) v = rnd_bf16(seed, 1.f);
+  } else {      // f32: the same values, as (bf16 bits << 16) with random low mantissa halves
+    auto fill = [&](std::vector<unsigned short>& v, float amp) {
+      for (size_t i = 0; i + 1 < v.size(); i += 2) { v[i] = rnd_bf16(seed, 1.f); v[i + 1] = rnd_bf16(seed, amp); }
+    };
+    fill(hx, 1.f); fill(hw, 0.05f); fill(hr, 1.f);
+  }
   std::vector<float> hs(Co, 1.0f), hb(Co, 0.01f);
   void *dx, *dw, *dr, *dy, *dz; float *ds, *db; unsigned long long* dst;
   CK(hipMalloc(&dx, xb)); CK(hipMalloc(&dw, wb)); CK(hipMalloc(&dr, yb)); CK(hipMalloc(&dy, yb)); CK(hipMalloc(&dz, 256));
@@ -51,10 +60,10 @@ int main(int argc, char** argv) {
   a.stamps = nullptr;
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 20; ++i) CK(nbc::launch_conv_dma(a, 1, tile, st));
+  for (int i = 0; i < 20; ++i) CK(nbc::launch_conv_dma(a, prec, tile, st));
   CK(hipEventRecord(e0, st));
   const int reps = 50;
-  for (int i = 0; i < reps; ++i) CK(nbc::launch_conv_dma(a, 1, tile, st));
+  for (int i = 0; i < reps; ++i) CK(nbc::launch_conv_dma(a, prec, tile, st));
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps, flops = 2.0 * M * Co * (double)K * K * Ci;
@@ -69,7 +78,7 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(f0, st));
     for (int k = 0; k < nstreams; ++k) CK(hipStreamWaitEvent(ss[k], f0, 0));
     for (int i = 0; i < reps; ++i)
-      for (int k = 0; k < nstreams; ++k) { nbc::ConvArgs b = a; b.y = ys[k]; CK(nbc::launch_conv_dma(b, 1, tile, ss[k])); }
+      for (int k = 0; k < nstreams; ++k) { nbc::ConvArgs b = a; b.y = ys[k]; CK(nbc::launch_conv_dma(b, prec, tile, ss[k])); }
     for (int k = 0; k < nstreams; ++k) { CK(hipEventCreate(&done[k])); CK(hipEventRecord(done[k], ss[k])); CK(hipStreamWaitEvent(st, done[k], 0)); }
     CK(hipEventRecord(f1, st)); CK(hipEventSynchronize(f1));
     float ms2 = 0; CK(hipEventElapsedTime(&ms2, f0, f1));
@@ -77,15 +86,15 @@ int main(int argc, char** argv) {
                 flops / (ms2 * 1e3 / (reps * nstreams)) * 1e-6, us);
   }
   a.stamps = dst;
-  CK(nbc::launch_conv_dma(a, 1, tile, st));   // stamped launches: the last one is read
-  CK(nbc::launch_conv_dma(a, 1, tile, st));
+  CK(nbc::launch_conv_dma(a, prec, tile, st));   // stamped launches: the last one is read
+  CK(nbc::launch_conv_dma(a, prec, tile, st));
   CK(hipStreamSynchronize(st));
   std::vector<unsigned long long> h((size_t)nblk * 64);
   CK(hipMemcpy(h.data(), dst, (size_t)nblk * 512, hipMemcpyDeviceToHost));
   unsigned long long t0 = ~0ull, t1 = 0;
   for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 64]); t1 = std::max(t1, h[b * 64 + 6]); }
-  std::printf("shape %dx%d Ci %d Co %d k%d d%d res %d tile %d (%dx%d): %d blocks, %d K-steps | %.1f us/launch back-to-back, %.0f TF | stamped span %.1f us\n",
-              Hi, Wi, Ci, Co, K, dil, res, tile, nbc::conv_tile_rows(tile), nbc::conv_tile_cols(tile), nblk, ksteps, us,
+  std::printf("shape %dx%d Ci %d Co %d k%d d%d res %d %s tile %d (%dx%d): %d blocks, %d K-steps | %.1f us/launch back-to-back, %.0f TF | stamped span %.1f us\n",
+              Hi, Wi, Ci, Co, K, dil, res, prec == 1 ? "bf16" : "f32", tile, nbc::conv_tile_rows(tile), nbc::conv_tile_cols(tile), nblk, ksteps, us,
               flops / us * 1e-6, (t1 - t0) * 0.01);
   auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
   const char* names[10] = {"start (since first block)", "address set-up done", "prologue issued", "first K-step landed",
@@ -111,7 +120,8 @@ int main(int argc, char** argv) {
   {  // shader clock held inside the K loop: core cycles (s_memtime) per 100 MHz wall tick
     std::vector<double> ghz, util, fvm, fbar;
     double wvm[16] = {0}, wbar[16] = {0}; int wn = 0;
-    const double mfma_cyc_per_step = (double)nbc::conv_tile_rows(tile) * nbc::conv_tile_cols(tile) * 64.0 / (4 * 512.0);   // 512 MAC/clk/SIMD (bf16)
+    // MAC per K-step of the tile / (4 SIMDs x MAC per clock per SIMD: 512 bf16, 32 f32)
+    const double mfma_cyc_per_step = (double)nbc::conv_tile_rows(tile) * nbc::conv_tile_cols(tile) * (prec == 1 ? 64.0 / (4 * 512.0) : 32.0 / (4 * 32.0));
     for (int b = 0; b < nblk; ++b) {
       const double dt = (double)(h[b * 64 + 3] - h[b * 64 + 2]), dc = (double)(h[b * 64 + 12] - h[b * 64 + 11]);
       if (h[b * 64 + 2] == 0 || dt < 50) continue;
