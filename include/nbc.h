@@ -170,11 +170,19 @@ int nbc_remove_small_zones(nbc_ctx* ctx, void* labels_dev, int labels_dtype, int
 
 /* The resize of the reference's preprocessor (models.py:191-198): uint8 RGB [H,W,3] on the device ->
  * ToTensor (u8 / 255 in float32) -> skimage.transform.resize(order=3, mode='reflect',
- * anti_aliasing=False) to out_h x out_w (4-tap Catmull-Rom at factor*(i+0.5)-0.5, reflected borders,
- * clipped to the input range) -> float32 [out_h,out_w,3] on the device.  Bit-identical to the numpy
- * restatement in neuralbarkcalculator_amd/predict.py, which scikit-image 0.18.3 fixtures pin. */
+ * anti_aliasing=False) to out_h x out_w (4-tap Catmull-Rom, all arithmetic in float32 like scikit-image's
+ * compiled warp, reflected borders, clipped to the input range) -> float32 [out_h,out_w,3] on the device.
+ * Bit-identical to the numpy restatement in neuralbarkcalculator_amd/predict.py, which equals
+ * scikit-image 0.18.3's output value for value on the committed fixtures. */
 int nbc_resize_cubic_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, float* dst_dev, int out_h, int out_w,
                         void* hip_stream);
+/* The same resize followed by what the reference does with its result (models.py:199-203), for a square
+ * target: dst_u8_dev uint8 [out_h,out_w,3] = the bytes skimage.io.imsave writes for that float image
+ * (uint8(float64(x) * 255 + 0.499999999), imageio's float -> uint8 path), and row_lit_dev (nullable, int32
+ * [out_h]) = per row the number of pixels whose float32 channel sum exceeds 1e-3, i.e. trim_black's `lit`
+ * test (models.py:158-159); the caller drops the leading / trailing rows with count / out_w <= 0.85. */
+int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_u8_dev, int32_t* row_lit_dev,
+                      int out_h, int out_w, void* hip_stream);
 
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
  * register-staged reference kernel; tile = -1 (per-layer choice) or 0..11 = 128x64, 128x128,

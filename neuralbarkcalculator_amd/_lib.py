@@ -63,6 +63,8 @@ SIGNATURES = {
     "nbc_remove_small_zones": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p]),
     "nbc_resize_cubic_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "nbc_preprocess_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p]),
     "nbc_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_void_p]),
     "nbc_get_plan_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),

@@ -688,7 +688,19 @@ int nbc_resize_cubic_u8(nbc_ctx* c, const uint8_t* src_dev, int H, int W, float*
   NBC_HIP(hipSetDevice(c->device));
   if (!c->scratch256) NBC_HIP(hipMalloc(&c->scratch256, 256));
   unsigned* minmax = static_cast<unsigned*>(c->scratch256);
-  NBC_HIP(launch_resize_cubic_u8(src_dev, H, W, dst_dev, out_h, out_w, minmax, static_cast<hipStream_t>(hip_stream)));
+  NBC_HIP(launch_resize_cubic_u8(src_dev, H, W, dst_dev, nullptr, nullptr, out_h, out_w, minmax, static_cast<hipStream_t>(hip_stream)));
+  return NBC_OK;
+}
+
+int nbc_preprocess_u8(nbc_ctx* c, const uint8_t* src_dev, int H, int W, uint8_t* dst_u8_dev, int32_t* row_lit_dev, int out_h,
+                      int out_w, void* hip_stream) {
+  if (!c || !src_dev || !dst_u8_dev) return set_error(NBC_ERR_INVALID, "nbc_preprocess_u8: null argument");
+  if (H < 1 || W < 1 || out_h < 1 || out_w < 1) return set_error(NBC_ERR_INVALID, "nbc_preprocess_u8: bad shape");
+  NBC_HIP(hipSetDevice(c->device));
+  if (!c->scratch256) NBC_HIP(hipMalloc(&c->scratch256, 256));
+  unsigned* minmax = static_cast<unsigned*>(c->scratch256);
+  NBC_HIP(launch_resize_cubic_u8(src_dev, H, W, nullptr, dst_u8_dev, row_lit_dev, out_h, out_w, minmax,
+                                 static_cast<hipStream_t>(hip_stream)));
   return NBC_OK;
 }
 

@@ -66,10 +66,11 @@ hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int 
 // 2 -> 1 remap and per-class counts afterwards.  Workspaces: bg N*H*W bytes, parent and size N*H*W ints.
 hipError_t launch_remove_small_zones(void* labels, int labels_i64, int N, int H, int W, int min_pixels, int exclude_nodes,
                                      unsigned char* bg, int* parent, int* size, unsigned long long* counts, hipStream_t s);
-// Preprocessor resize (models.py:191-198): uint8 HWC [H,W,3] -> ToTensor -> skimage cubic resize with
-// reflected borders, clipped to the input range -> float32 HWC [out_h,out_w,3].  minmax: two uints of scratch.
-hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, int out_h, int out_w, unsigned* minmax,
-                                  hipStream_t s);
+// Preprocessor (models.py:191-203): uint8 HWC [H,W,3] -> ToTensor -> skimage cubic resize with reflected borders,
+// clipped to the input range -> any of: float32 HWC [out_h,out_w,3]; its uint8 form as imsave writes it; per output
+// row the number of pixels trim_black counts as lit.  minmax: two uints of scratch.
+hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, uint8_t* dst_u8, int* row_lit, int out_h, int out_w,
+                                  unsigned* minmax, hipStream_t s);
 // NHWC elements -> float32 NCHW (debug read-back of activations).
 hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W, int C, int precision,
                                    hipStream_t s);

@@ -419,11 +419,12 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restric
 }
 
 // ---- preprocessor (next-row N4): models.py:191-198, skimage.transform.resize(order=3, mode='reflect',
-// anti_aliasing=False) of the ToTensor'd image, as restated and pinned in neuralbarkcalculator_amd/predict.py
-// (resize_bicubic_reflect): output pixel i samples the input at factor*(i+0.5)-0.5 with a separable
-// 4-tap Catmull-Rom kernel, reflected borders, clipped to the input range.  Every rounding of the numpy
-// restatement is reproduced (coordinates and offsets in f32, the two value differences in f32, the
-// polynomial in f64 without contraction, each pass rounded to f32), so the output is bit-identical.
+// anti_aliasing=False) of the ToTensor'd image, as scikit-image 0.18.3's compiled _warp_fast evaluates it for a
+// float32 image (restated and pinned value for value in neuralbarkcalculator_amd/predict.py,
+// resize_bicubic_reflect): EVERYTHING in f32, one rounding per operation, no contraction -- the sample
+// position f*i + (f/2 - 1/2) with f and the offset rounded from double first, its fractional part, the
+// 4 x 4 taps (reflected borders) through the Catmull-Rom polynomial in its source order row-wise then
+// column-wise, the clip to the input range.  Bit-identical to the numpy form, hence to scikit-image.
 __device__ __forceinline__ int reflect_index(int i, int n) {
   if (n == 1) return 0;
   const int period = 2 * (n - 1);
@@ -431,15 +432,22 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
   if (i < 0) i += period;
   return i >= n ? period - i : i;
 }
-__device__ __forceinline__ float cubic_f32(double x, float f0, float f1, float f2, float f3) {
-  const double d20 = (double)__fsub_rn(f2, f0), d12 = (double)__fsub_rn(f1, f2);
-  const double a0 = f0, a1 = f1, a2 = f2, a3 = f3;
-  // f1 + 0.5*x*(d20 + x*(2*f0 - 5*f1 + 4*f2 - f3 + x*(3*d12 + f3 - f0))), numpy's left-to-right order
-  const double inner = __dsub_rn(__dadd_rn(__dmul_rn(3.0, d12), a3), a0);
-  const double mid = __dadd_rn(__dsub_rn(__dadd_rn(__dsub_rn(__dmul_rn(2.0, a0), __dmul_rn(5.0, a1)), __dmul_rn(4.0, a2)), a3),
-                               __dmul_rn(x, inner));
-  const double outer = __dadd_rn(d20, __dmul_rn(x, mid));
-  return (float)__dadd_rn(a1, __dmul_rn(__dmul_rn(0.5, x), outer));
+// (plain operators under `fp contract(off)`: every product and sum is rounded on its own; the __f*_rn
+// intrinsics inline to operations that carry the library's own contraction flags and were fused)
+__device__ __forceinline__ float cubic_f32(float x, float f0, float f1, float f2, float f3) {
+#pragma clang fp contract(off)
+  // f1 + 0.5*x*(f2 - f0 + x*(2*f0 - 5*f1 + 4*f2 - f3 + x*(3*(f1 - f2) + f3 - f0))), left to right as written
+  const float d12 = f1 - f2;
+  const float t3 = 3.0f * d12;
+  const float inner = (t3 + f3) - f0;
+  const float p2 = 2.0f * f0, p5 = 5.0f * f1, p4 = 4.0f * f2;
+  const float xi = x * inner;
+  const float mid = (((p2 - p5) + p4) - f3) + xi;
+  const float xm = x * mid;
+  const float outer = (f2 - f0) + xm;
+  const float hx = 0.5f * x;
+  const float ho = hx * outer;
+  return f1 + ho;
 }
 
 __global__ void minmax_u8_kernel(const uint8_t* __restrict__ x, size_t n, unsigned* __restrict__ mm) {
@@ -458,32 +466,61 @@ __global__ void minmax_u8_kernel(const uint8_t* __restrict__ x, size_t n, unsign
   if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
 }
 
-// grid = (ceil(out_w*3 / 256), out_h); a thread owns one channel of one output pixel
+// grid = (ceil(out_w / 256), out_h); a thread owns one output pixel (three channels).
+// Outputs, each optional: the float32 image (what skimage's resize returns), its uint8 form as
+// skimage.io.imsave writes it through imageio (uint8(float64(x) * 255 + 0.499999999), models.py:203), and per
+// output row the number of pixels trim_black calls lit (float32 channel sum > 1e-3, models.py:158-159).
 __global__ __launch_bounds__(256) void resize_cubic_kernel(const uint8_t* __restrict__ src, int H, int W, float* __restrict__ dst,
+                                                           uint8_t* __restrict__ dst_u8, int* __restrict__ row_lit,
                                                            int out_h, int out_w, const unsigned* __restrict__ mm) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int ox = e / 3, c = e - ox * 3, oy = blockIdx.y;
-  if (ox >= out_w) return;
-  const float ry = (float)__dsub_rn(__dmul_rn(__ddiv_rn((double)H, (double)out_h), __dadd_rn((double)oy, 0.5)), 0.5);
-  const float rx = (float)__dsub_rn(__dmul_rn(__ddiv_rn((double)W, (double)out_w), __dadd_rn((double)ox, 0.5)), 0.5);
-  const int y0 = (int)floorf(ry), x0 = (int)floorf(rx);
-  const double ty = (double)__fsub_rn(ry, (float)y0), tx = (double)__fsub_rn(rx, (float)x0);
-  int cols[4];
+#pragma clang fp contract(off)
+  const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y;
+  bool lit = false;
+  if (ox < out_w) {
+    const double fy = __ddiv_rn((double)H, (double)out_h), fx = __ddiv_rn((double)W, (double)out_w);
+    const double hy = fy * 0.5, hx = fx * 0.5;
+    const float by = (float)(hy - 0.5), bx = (float)(hx - 0.5);
+    const float my = (float)fy * (float)oy, mx = (float)fx * (float)ox;
+    const float ry = my + by, rx = mx + bx;
+    const int y0 = (int)floorf(ry), x0 = (int)floorf(rx);
+    const float ty = ry - (float)y0, tx = rx - (float)x0;
+    int cols[4], rows[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) cols[k] = reflect_index(x0 + k - 1, W);
-  float fr[4];
+    for (int k = 0; k < 4; ++k) { cols[k] = reflect_index(x0 + k - 1, W); rows[k] = reflect_index(y0 + k - 1, H); }
+    const float lo = __fdiv_rn((float)mm[0], 255.0f), hi = __fdiv_rn((float)mm[1], 255.0f);
+    float v[3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint8_t* row = src + (size_t)reflect_index(y0 + k - 1, H) * W * 3 + c;
-    float f[4];
+    for (int c = 0; c < 3; ++c) {
+      float fr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = __fdiv_rn((float)row[(size_t)cols[j] * 3], 255.0f);      // ToTensor
-    fr[k] = cubic_f32(tx, f[0], f[1], f[2], f[3]);
+      for (int k = 0; k < 4; ++k) {
+        const uint8_t* row = src + (size_t)rows[k] * W * 3 + c;
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = __fdiv_rn((float)row[(size_t)cols[j] * 3], 255.0f);      // ToTensor
+        fr[k] = cubic_f32(tx, f[0], f[1], f[2], f[3]);
+      }
+      const float r = cubic_f32(ty, fr[0], fr[1], fr[2], fr[3]);
+      v[c] = r < lo ? lo : (r > hi ? hi : r);                // np.clip(out, img.min(), img.max())
+    }
+    const size_t o = ((size_t)oy * out_w + ox) * 3;
+    if (dst) { dst[o] = v[0]; dst[o + 1] = v[1]; dst[o + 2] = v[2]; }
+    if (dst_u8) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double q255 = (double)v[c] * 255.0;
+        double q = q255 + 0.499999999;
+        q = q < 0.0 ? 0.0 : (q > 255.0 ? 255.0 : q);
+        dst_u8[o + c] = (uint8_t)(int)q;                       // astype(uint8): truncation
+      }
+    }
+    const float s01 = v[0] + v[1];
+    lit = (s01 + v[2]) > 1e-3f;                              // np.sum(image, axis=-1) > 1e-3 in float32
   }
-  float v = cubic_f32(ty, fr[0], fr[1], fr[2], fr[3]);
-  const float lo = __fdiv_rn((float)mm[0], 255.0f), hi = __fdiv_rn((float)mm[1], 255.0f);
-  v = v < lo ? lo : (v > hi ? hi : v);                     // np.clip(out, img.min(), img.max())
-  dst[((size_t)oy * out_w + ox) * 3 + c] = v;
+  if (row_lit) {
+    const unsigned long long m = __ballot(lit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&row_lit[oy], (int)__popcll(m));
+  }
 }
 
 inline int grid_for(size_t total, int block) {
@@ -564,19 +601,22 @@ hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int 
   return hipGetLastError();
 }
 
-hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, int out_h, int out_w, unsigned* minmax,
-                                  hipStream_t s) {
+hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, uint8_t* dst_u8, int* row_lit, int out_h, int out_w,
+                                  unsigned* minmax, hipStream_t s) {
   if (H < 1 || W < 1 || out_h < 1 || out_w < 1 || out_h > 65535) return hipErrorInvalidValue;
-  // min starts at 255 (0xFF in every byte of the word's low byte is enough: values are <= 255), max at 0:
-  // two device-side fills, no host source buffer that would have to outlive the call
+  // min starts at 255, max at 0: two device-side fills, no host source buffer that would have to outlive the call
   hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(minmax), 255, 1, s);
   if (e != hipSuccess) return e;
   e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(minmax + 1), 0, 1, s);
   if (e != hipSuccess) return e;
+  if (row_lit) {
+    e = hipMemsetAsync(row_lit, 0, sizeof(int) * (size_t)out_h, s);
+    if (e != hipSuccess) return e;
+  }
   const size_t n = (size_t)H * W * 3;
   hipLaunchKernelGGL(minmax_u8_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, n, minmax);
-  hipLaunchKernelGGL(resize_cubic_kernel, dim3((out_w * 3 + 255) / 256, out_h), dim3(256), 0, s, src, H, W, dst, out_h, out_w,
-                     minmax);
+  hipLaunchKernelGGL(resize_cubic_kernel, dim3((out_w + 255) / 256, out_h), dim3(256), 0, s, src, H, W, dst, dst_u8, row_lit, out_h,
+                     out_w, minmax);
   return hipGetLastError();
 }
 

@@ -202,6 +202,22 @@ class FCNResNet50:
                                                      out.data_ptr(), int(out_h), int(out_w), stream), "nbc_resize_cubic_u8")
         return out
 
+    def preprocess_u8(self, image: torch.Tensor, out_h: int, out_w: int):
+        """``resize_cubic_u8`` followed by the float -> uint8 conversion of ``skimage.io.imsave`` (models.py:203)
+        and ``trim_black``'s per-row lit-pixel counts (models.py:158-161), all on the device.  Returns
+        ``(uint8 [out_h,out_w,3], int32 [out_h])``."""
+        self._require_ctx()
+        if image.device != self.device or image.dtype != torch.uint8 or image.dim() != 3 or image.shape[2] != 3 \
+                or not image.is_contiguous():
+            raise ValueError("image must be a contiguous uint8 [H,W,3] tensor on %s" % (self.device,))
+        out = torch.empty((int(out_h), int(out_w), 3), dtype=torch.uint8, device=self.device)
+        lit = torch.empty((int(out_h),), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.nbc_preprocess_u8(self._ctx, image.data_ptr(), int(image.shape[0]), int(image.shape[1]),
+                                                   out.data_ptr(), lit.data_ptr(), int(out_h), int(out_w), stream), "nbc_preprocess_u8")
+        return out, lit
+
     def upsample_argmax(self, lowres: torch.Tensor, size: Tuple[int, int], exclude_nodes: bool = False,
                         labels_dtype: torch.dtype = torch.int64, return_logits: bool = False):
         """Tail of the path on caller-supplied low-res logits f32 ``[N,3,h,w]``:

@@ -16,10 +16,10 @@ accelerated model call:
   ``models.py:321``; reproduced verbatim).  The matplotlib figure of ``models.py:280-347``
   (about 10 s per image) is not produced.
 
-Multi-GPU (one process per GPU, ``torch.distributed`` over RCCL): rank r takes images
-``r, r+W, ...`` of the sorted list; rank 0 alone reads the checkpoint and broadcasts the packed
-weights; every rank fills int64 rows ``(global_idx, H, W, count_1, count_2)`` which one
-``all_gather`` brings to rank 0 for the CSV.  No collective sits in the per-image path.
+Multi-GPU (one process per GPU, ``torch.distributed`` over RCCL; ``--gpus N`` starts the ranks): the
+sorted list is cut into contiguous, pixel-balanced shards; rank 0 alone reads the checkpoint and
+broadcasts the packed weights; every rank fills int64 rows ``(global_idx, H, W, count_1, count_2)``
+which one ``all_gather`` brings to rank 0 for the CSV.  No collective sits in the per-image path.
 """
 from __future__ import annotations
 
@@ -75,14 +75,14 @@ def trim_black(image: np.ndarray) -> np.ndarray:
     return image[first:last]
 
 
-def _cubic(x, f0, f1, f2, f3, dt=np.float64):
+def _cubic(x, f0, f1, f2, f3):
     """scikit-image's cubic_interpolation (Catmull-Rom, a = -0.5): values at -1, 0, 1, 2; x in [0, 1].
-    C evaluation rules of its Cython source for an image of float type ``dt``: the two differences of
-    image values are taken in ``dt``, everything that meets a (double) literal in double."""
-    d20 = (f2.astype(dt) - f0.astype(dt)).astype(np.float64)
-    d12 = (f1.astype(dt) - f2.astype(dt)).astype(np.float64)
-    f0, f1, f2, f3 = (f.astype(np.float64) for f in (f0, f1, f2, f3))
-    return f1 + 0.5 * x * (d20 + x * (2.0 * f0 - 5.0 * f1 + 4.0 * f2 - f3 + x * (3.0 * d12 + f3 - f0)))
+    Evaluated in the image's own float type throughout, in the order its Cython source is written
+    (``f1 + 0.5*x*(f2 - f0 + x*(2*f0 - 5*f1 + 4*f2 - f3 + x*(3*(f1 - f2) + f3 - f0)))``), one rounding per
+    operation: this is what the compiled _warp_fast does for a float32 image (checked value for value
+    against scikit-image 0.18.3, tests/golden/preprocess_*.npz ``float32``)."""
+    t = x.dtype.type
+    return f1 + t(0.5) * x * (f2 - f0 + x * (t(2.0) * f0 - t(5.0) * f1 + t(4.0) * f2 - f3 + x * (t(3.0) * (f1 - f2) + f3 - f0)))
 
 
 def _reflect(i: np.ndarray, n: int) -> np.ndarray:
@@ -96,80 +96,170 @@ def _reflect(i: np.ndarray, n: int) -> np.ndarray:
 
 def resize_bicubic_reflect(image: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     """``skimage.transform.resize(image, (out_h, out_w), order=3, mode='reflect',
-    anti_aliasing=False)`` (models.py:194-198) for a float HWC image: output pixel i samples the
-    input at ``factor * (i + 0.5) - 0.5`` with a separable 4-tap Catmull-Rom kernel in the image's
-    own float type, reflected borders, result clipped to the input range (``clip=True``).  Pinned by
-    scikit-image 0.18.3 fixtures (tests/golden/preprocess_*.npz)."""
+    anti_aliasing=False)`` (models.py:194-198) for a float HWC image, as scikit-image 0.18.3 computes it:
+    ``resize`` builds the metric transform ``[[fx, 0, fx/2 - 1/2], [0, fy, fy/2 - 1/2]]`` (f = in / out) in
+    double, ``warp`` casts it to the image's float type and ``_warp_fast`` evaluates everything in that
+    type: the sample position of output pixel i is ``f * i + (f/2 - 1/2)`` (one product, one sum, each
+    rounded), its fractional part is taken in the same type, the 4 x 4 taps (reflected borders) go
+    through ``_cubic`` row-wise then column-wise, and the result is clipped to the input range
+    (``clip=True``).  Bit-identical to scikit-image's output on the committed fixtures, integer and
+    non-integer zoom factors alike."""
     h, w = image.shape[:2]
     dt = image.dtype if image.dtype in (np.float32, np.float64) else np.float64
+    t = np.dtype(dt).type
     img = image.astype(dt, copy=False)
-    # scikit-image's _warp_fast works in the image's float type (float32 after ToTensor): sample
-    # coordinates and the two fractional offsets are rounded to it; each cubic_interpolation call
-    # evaluates in double (its literals are doubles) and returns the image's type.
-    ry = ((h / out_h) * (np.arange(out_h) + 0.5) - 0.5).astype(dt)
-    rx = ((w / out_w) * (np.arange(out_w) + 0.5) - 0.5).astype(dt)
+    fy, fx = h / out_h, w / out_w                                    # Python doubles, like resize's `factors`
+    ry = t(fy) * np.arange(out_h, dtype=dt) + t(fy * 0.5 - 0.5)
+    rx = t(fx) * np.arange(out_w, dtype=dt) + t(fx * 0.5 - 0.5)
     y0 = np.floor(ry).astype(np.int64)
     x0 = np.floor(rx).astype(np.int64)
-    ty = (ry - y0.astype(dt)).astype(np.float64).reshape(-1, 1, 1)
-    tx = (rx - x0.astype(dt)).astype(np.float64).reshape(1, -1, 1)
+    ty = (ry - y0.astype(dt)).reshape(-1, 1, 1)
+    tx = (rx - x0.astype(dt)).reshape(1, -1, 1)
     cols = [_reflect(x0 + k - 1, w) for k in range(4)]
     fr = []
     for k in range(4):
         rows = img[_reflect(y0 + k - 1, h)]
-        fr.append(_cubic(tx, *[rows[:, c] for c in cols], dt=dt).astype(dt))
-    out = _cubic(ty, *fr, dt=dt).astype(dt)
+        fr.append(_cubic(tx, *[rows[:, c] for c in cols]))
+    out = _cubic(ty, *fr)
+    assert out.dtype == dt
     return np.clip(out, img.min(), img.max())
+
+
+def _float_to_u8(image: np.ndarray) -> np.ndarray:
+    """``skimage.io.imsave`` of a float image in [0, 1] (models.py:203) goes through imageio's
+    ``image_as_uint``: ``uint8(float64(x) * 255 + 0.499999999)`` (exact halves round down)."""
+    return np.clip(image.astype(np.float64) * 255.0 + 0.499999999, 0, 255).astype(np.uint8)
+
+
+# uint8 -> ToTensor (float32 / 255) -> imsave's float -> uint8: a 256-entry table (it is the identity, which
+# tests/test_driver.py asserts; the table keeps the code honest should a platform's float division differ)
+_U8_ROUND_TRIP = _float_to_u8(np.arange(256, dtype=np.uint8).astype(np.float32) / np.float32(255))
+_U8_ROUND_TRIP_IS_IDENTITY = bool(np.array_equal(_U8_ROUND_TRIP, np.arange(256, dtype=np.uint8)))
+
+
+def _trim_rows(clear: np.ndarray) -> Tuple[int, int]:
+    """models.py:162-166: first / one-past-last row of the ``clear`` (enough lit pixels) flags."""
+    first = int(np.argmax(clear))
+    last = clear.shape[0] - int(np.argmax(clear[::-1]))
+    return first, last
 
 
 def preprocess_image(img_u8: np.ndarray, target_size: int = 1024, model=None) -> np.ndarray:
     """models.py:191-203 for one decoded RGB image: ToTensor (u8 -> float32 / 255), resize to
     ``target_size`` x ``target_size`` when either side is larger, ``trim_black`` when square,
-    float -> uint8 like ``skimage.io.imsave`` does through imageio (``uint8(float64(x) * 255 + 0.499999999)``:
-    the "Lossy conversion from float32 to uint8" path, which rounds exact halves down).  With ``model``
-    (an ``FCNResNet50`` on a device) the resize runs there."""
-    if max(img_u8.shape[:2]) > target_size and model is not None:
-        # the resize on the device (nbc_resize_cubic_u8, bit-identical to the numpy form below, which
-        # takes ~1.1 s for a 4096^2 image)
+    float -> uint8 like ``skimage.io.imsave`` does through imageio.  Byte-identical to what scikit-image
+    0.18.3 writes (tests/golden/preprocess_*.npz).  Three routes, same bytes:
+
+    * no resize needed: the float round trip maps every byte to itself and a pixel is "lit" (float32 channel
+      sum > 1e-3) exactly when one of its bytes is non-zero, so the image is trimmed as uint8;
+    * resize with ``model`` (an ``FCNResNet50`` on a device): resize, float -> uint8 and the per-row lit
+      counts on the device (``nbc_preprocess_u8``), the row trim here;
+    * resize without a device: the numpy restatement (about 1 s for a 4096 x 4096 scan)."""
+    if max(img_u8.shape[:2]) <= target_size:
+        out = img_u8 if _U8_ROUND_TRIP_IS_IDENTITY else _U8_ROUND_TRIP[img_u8]
+        if out.shape[0] == out.shape[1]:
+            lit = (out[..., 0] | out[..., 1] | out[..., 2]) != 0     # == out.any(axis=-1), ten times faster
+            first, last = _trim_rows(np.mean(lit, axis=-1) > 0.85)
+            out = out[first:last]
+        return np.ascontiguousarray(out)
+    if model is not None:
         import torch
         dev_img = torch.from_numpy(np.ascontiguousarray(img_u8)).to(model.device)
-        image = model.resize_cubic_u8(dev_img, target_size, target_size).cpu().numpy()
-    else:
-        image = img_u8.astype(np.float32) / np.float32(255)
-        if max(image.shape[:2]) > target_size:
-            image = resize_bicubic_reflect(image, target_size, target_size)
+        out_dev, lit_dev = model.preprocess_u8(dev_img, target_size, target_size)
+        out, lit = out_dev.cpu().numpy(), lit_dev.cpu().numpy()
+        first, last = _trim_rows(lit / np.float64(target_size) > 0.85)          # np.mean of booleans: float64 count / n
+        return np.ascontiguousarray(out[first:last])
+    image = resize_bicubic_reflect(img_u8.astype(np.float32) / np.float32(255), target_size, target_size)
     if image.shape[0] == image.shape[1]:
         image = trim_black(image)
-    return np.clip(image.astype(np.float64) * 255.0 + 0.499999999, 0, 255).astype(np.uint8)
+    return _float_to_u8(image)
+
+
+def _decode_bmp24(buf: bytes):
+    """Uncompressed 24-bit BMP (what the scanner writes, predict.py:15-17) straight into an RGB array: three
+    strided numpy copies (which drop the GIL) instead of PIL's decoder loop; None for any other flavour."""
+    import struct
+    if len(buf) < 54 or buf[:2] != b"BM":
+        return None
+    off, = struct.unpack_from("<I", buf, 10)
+    hdr, w, h, planes, bpp, comp = struct.unpack_from("<IiiHHI", buf, 14)
+    if hdr < 40 or planes != 1 or bpp != 24 or comp != 0 or w <= 0 or h == 0:
+        return None
+    rows, stride = abs(h), (w * 3 + 3) & ~3
+    if off + stride * rows > len(buf):
+        return None
+    a = np.frombuffer(buf, np.uint8, stride * rows, off).reshape(rows, stride)[:, : w * 3].reshape(rows, w, 3)
+    if h > 0:
+        a = a[::-1]                                  # bottom-up rows
+    out = np.empty((rows, w, 3), dtype=np.uint8)
+    out[..., 0], out[..., 1], out[..., 2] = a[..., 2], a[..., 1], a[..., 0]     # BGR -> RGB
+    return out
+
+
+def _decode_rgb(path: str) -> np.ndarray:
+    """pil_loader (dataset.py:82-90): the file as an RGB uint8 array (own, contiguous copy)."""
+    import io
+    from PIL import Image
+    with open(path, "rb") as f:
+        buf = f.read()
+    img = _decode_bmp24(buf)
+    if img is None:
+        img = np.array(Image.open(io.BytesIO(buf)).convert("RGB"))
+    return img
+
+
+def _host_workers() -> int:
+    return max(1, min(32, int(os.environ.get("NBC_HOST_WORKERS", "16"))))
+
+
+def _png_level(kind: str) -> int:
+    """zlib level of the PNGs the driver writes.  The files carry pixel values (models.py:203,349-356 pin
+    values, not bytes): processed frames default to stored (level 0: noise-like photographs barely
+    compress and deflate costs 100 ms per 1024x1024 frame), label maps to level 1 (a few ms, 20x smaller)."""
+    return int(os.environ.get("NBC_PNG_LEVEL_" + kind.upper(), "0" if kind == "processed" else "1"))
 
 
 def preprocess_images(root: str, target_size: int = 1024, model=None) -> None:
-    """models.py:173-203: decode, resize / trim, save as PNG under processed/.  Decoding and PNG
-    encoding (the bulk: ~0.2 s per 1024x1024 image) run on a small thread pool; a device resize, when
-    ``model`` is given, is serialised (one context, not thread-safe)."""
+    """models.py:173-203 as a stand-alone pass (``--only_preprocess``): decode, resize / trim, save as PNG
+    under processed/, on a thread pool; a device resize, when ``model`` is given, is serialised."""
     import threading
     from concurrent.futures import ThreadPoolExecutor
-    from PIL import Image
+    from .pngio import write_png
     lock = threading.Lock()
 
     def one(item):
         path, name, wood = item
-        with open(path, "rb") as f:
-            img = np.asarray(Image.open(f).convert("RGB"))                 # dataset.py:82-90
+        img = _decode_rgb(path)
         if model is not None and max(img.shape[:2]) > target_size:
             with lock:
                 out = preprocess_image(img, target_size, model)
         else:
             out = preprocess_image(img, target_size)
-        Image.fromarray(out, mode="RGB").save(os.path.join(root, "processed", "samples", wood, name))
+        write_png(os.path.join(root, "processed", "samples", wood, name), out, _png_level("processed"))
 
-    workers = max(1, min(32, int(os.environ.get("NBC_HOST_WORKERS", "8"))))
-    with ThreadPoolExecutor(max_workers=workers) as pool:
+    with ThreadPoolExecutor(max_workers=_host_workers()) as pool:
         list(pool.map(one, list_images(root)))
 
 
 def shard_indices(n: int, rank: int, world: int) -> List[int]:
-    """Images of rank ``rank``: r, r+W, r+2W, ...."""
+    """Round-robin shard: images r, r+W, r+2W, ... (frames of equal size: bench.py)."""
     return list(range(rank, n, world))
+
+
+def shard_by_pixels(pixels: Sequence[int], world: int) -> List[List[int]]:
+    """Contiguous, pixel-balanced shards of the sorted image list (folders of height-trimmed
+    or differently sized scans): image i goes to the rank whose share of the total pixel count contains the
+    midpoint of i's own span.  Every rank gets a contiguous range; ranges are empty only when there are
+    fewer images than ranks."""
+    total = float(sum(pixels))
+    shards: List[List[int]] = [[] for _ in range(world)]
+    acc = 0.0
+    for i, p in enumerate(pixels):
+        mid = acc + 0.5 * p
+        r = min(world - 1, int(mid * world / total)) if total > 0 else i % world
+        shards[r].append(i)
+        acc += p
+    return shards
 
 
 def stats_row(name: str, wood: str, h: int, w: int, count_1: int, count_2: int) -> List[str]:
@@ -196,11 +286,13 @@ def label_png(labels: np.ndarray) -> np.ndarray:
     return out
 
 
-def gather_rows(local_rows: np.ndarray, n_total: int, world: int, dist=None, device=None) -> np.ndarray:
+def gather_rows(local_rows: np.ndarray, n_total: int, world: int, dist=None, device=None, cap: int = None) -> np.ndarray:
     """all_gather of fixed-size per-rank row buffers; returns the rows sorted by global index.
-    ``local_rows``: int64 [k, ROW_WIDTH] with k <= ceil(n_total / world)."""
+    ``local_rows``: int64 [k, ROW_WIDTH] with k <= ``cap`` (default ceil(n_total / world), the round-robin
+    bound; pixel-balanced shards pass the largest shard's size)."""
     import torch
-    cap = (n_total + world - 1) // world if n_total else 0
+    if cap is None:
+        cap = (n_total + world - 1) // world if n_total else 0
     buf = torch.full((max(cap, 1), ROW_WIDTH), -1, dtype=torch.int64)
     if len(local_rows):
         buf[: len(local_rows)] = torch.from_numpy(np.asarray(local_rows, dtype=np.int64))
@@ -217,12 +309,47 @@ def gather_rows(local_rows: np.ndarray, n_total: int, world: int, dist=None, dev
     return allrows[np.argsort(allrows[:, 0], kind="stable")]
 
 
+def plan_items(root: str) -> List[dict]:
+    """What the reference's two passes end up predicting, in its order: every file that will exist under
+    processed/samples/<wood>/ once the preprocessor has run (models.py:173-189 writes
+    ``fname.replace("bmp", "png")`` for each sample, a later sample of the same output name overwriting an
+    earlier one; files already there stay), listed like dataset.py:41-68 lists them."""
+    by_key = {}
+    for path, name, wood in list_images(root):
+        by_key[(wood, name)] = {"name": name, "wood": wood, "src": path}
+    pdir = os.path.join(root, "processed")
+    if os.path.isdir(os.path.join(pdir, "samples")):
+        for path, name, wood in list_images(pdir):
+            key = (wood, name.replace("bmp", "png"))
+            if key not in by_key:                      # stale processed file without a sample: predicted as it is
+                by_key[key] = {"name": key[1], "wood": wood, "src": None, "processed": path}
+    order = {w: i for i, w in enumerate(WOOD_TYPES)}
+    items = sorted(by_key.values(), key=lambda d: (order[d["wood"]], d["name"]))
+    for d in items:
+        d.setdefault("processed", os.path.join(pdir, "samples", d["wood"], d["name"]))
+    return items
+
+
 def predict_folder(root: str, model_path: str = "./best_model.pt", precision: str = "fp32",
-                   exclude_nodes: bool = False, small_zones: bool = True, device_index: int = None) -> None:
-    """predict.py:51-58 + models.py:230-364 with the model call on the MI355X path."""
+                   exclude_nodes: bool = False, small_zones: bool = True, device_index: int = None,
+                   batch: int = None, window: int = 64, target_size: int = 1024) -> dict:
+    """predict.py:51-58 + models.py:230-364 with the model call on the MI355X path.
+
+    One pass per image instead of the reference's two (preprocess everything, then predict everything):
+    a rank decodes and preprocesses its own images on a host thread pool (writing processed/ as the
+    reference does), hands the uint8 frames to the GPU in windows of ``window`` images while the pool
+    already works on the next window, runs equal-sized frames of a window as batches of up to ``batch``,
+    and writes each label PNG from the pool as soon as its labels are on the host (pinned double
+    buffer, asynchronous copy).  Returns timing / count statistics of this rank."""
+    import time
     import torch
+    from collections import defaultdict
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
     from PIL import Image
     from .model import FCNResNet50
+    from .pngio import write_png
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if device_index is None else device_index
@@ -234,68 +361,193 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         if not dist.is_initialized():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if batch is None:
+        batch = 8 if precision == "bf16" else 2
 
     model = FCNResNet50(precision)
     model.to(dev)
+    pre_model = FCNResNet50(precision).to(dev)      # its own context: the pool's device resizes never touch the predictor's
     if rank == 0:
         generate_folders(root)
-        preprocess_images(root, model=model)         # the resize of oversize images runs on the device
     if dist is not None:
         dist.barrier()
     if rank == 0:                                    # only one rank touches the checkpoint
         model.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True))
-        model.to(dev)
     if dist is not None:
         model.broadcast_weights(src=0)
+    t_ready = time.perf_counter()
 
-    images = list_images(os.path.join(root, "processed"))
-    mine = shard_indices(len(images), rank, world)
+    items = plan_items(root)
+    n_total = len(items)
+    workers = _host_workers()
+    pool = ThreadPoolExecutor(max_workers=workers)
+
+    def header_pixels(d):
+        with open(d["src"] or d["processed"], "rb") as f:
+            w, h = Image.open(f).size                # header only: nothing is decoded
+        return w * h
+    pixels = list(pool.map(header_pixels, items))
+    shards = shard_by_pixels(pixels, world)
+    mine = shards[rank]
     rows = np.zeros((len(mine), ROW_WIDTH), dtype=np.int64)
+    resize_lock = threading.Lock()
+    lvl_proc, lvl_lab = _png_level("processed"), _png_level("labels")
 
-    # The forward is ~1.4 ms per image and remove_small_zones ~0.14 ms on the device; decoding the PNG
-    # and writing the label PNG are tens of milliseconds of host work each.  They run on a small
-    # thread pool around the GPU loop (PIL and numpy release the GIL in their C code): a few images are
-    # decoded ahead and every image's PNG is handed off as soon as its labels are on the host.
-    from collections import deque
-    from concurrent.futures import ThreadPoolExecutor
+    prof = defaultdict(float)                        # seconds per stage, summed over threads (NBC_FOLDER_PROFILE=1 prints them)
+    clock = time.perf_counter
 
-    def load(gi):
-        with open(images[gi][0], "rb") as f:
-            return np.array(Image.open(f).convert("RGB"))           # own, writable, contiguous copy
+    def prepare(gi):
+        """Pool: decode + preprocess + write processed/ -> the uint8 frame the model sees."""
+        d = items[gi]
+        t0 = clock()
+        if d["src"] is None:
+            return _decode_rgb(d["processed"])
+        img = _decode_rgb(d["src"])
+        t1 = clock()
+        if max(img.shape[:2]) > target_size:
+            with resize_lock:
+                out = preprocess_image(img, target_size, pre_model)
+        else:
+            out = preprocess_image(img, target_size)
+        t2 = clock()
+        write_png(d["processed"], out, lvl_proc)
+        t3 = clock()
+        prof["pool.decode"] += t1 - t0; prof["pool.preprocess"] += t2 - t1; prof["pool.write_processed"] += t3 - t2
+        return out
 
-    def finish(gi, lab, counts):
-        _, name, wood = images[gi]
-        Image.fromarray(label_png(lab), mode="L").save(os.path.join(root, "results", "outputs", wood, name))
-        return (gi, lab.shape[0], lab.shape[1], counts[0], counts[1])
+    def finish(k, gi, lab, c1, c2):
+        """Pool: label PNG (models.py:349-356) + the image's row."""
+        d = items[gi]
+        t0 = clock()
+        write_png(os.path.join(root, "results", "outputs", d["wood"], d["name"]), label_png(lab), lvl_lab)
+        rows[k] = (gi, lab.shape[0], lab.shape[1], c1, c2)
+        prof["pool.write_labels"] += clock() - t0
 
-    workers = max(1, min(32, int(os.environ.get("NBC_HOST_WORKERS", "8"))))
-    ahead = 2 * workers
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        loads = deque(pool.submit(load, gi) for gi in mine[:ahead])
-        done = []
-        for k, gi in enumerate(mine):
-            img = loads.popleft().result()
-            if k + ahead < len(mine):
-                loads.append(pool.submit(load, mine[k + ahead]))
-            x = torch.from_numpy(img)[None].to(dev)                  # uint8 NHWC; normalised on device
-            labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes, labels_dtype=torch.uint8,
-                                                  small_zones=small_zones)   # models.py:269-276 on the device
-            lab = labels[0].cpu().numpy()
-            cnt = (int(counts[0, 1]), int(counts[0, 2]))
-            done.append(pool.submit(finish, gi, lab, cnt))
-        for k, f in enumerate(done):
-            rows[k] = f.result()
+    # pinned double buffer for labels + counts coming back
+    ring = [None, None]
+    ring_ev = [torch.cuda.Event(), torch.cuda.Event()]
+    stage = [{"buf": None, "ev": torch.cuda.Event()}, {"buf": None, "ev": torch.cuda.Event()}]
+    pending = None                                   # (slot, [(k, gi)], n, h, w)
+    done = []
+    tuned = set()
+    shape_count = defaultdict(int)
+    n_batches = 0
 
-    allrows = gather_rows(rows, len(images), world, dist, dev)
+    def consume(p):
+        slot, members, n, h, w = p
+        ring_ev[slot].synchronize()
+        lab_host, cnt_host = ring[slot]
+        labs = lab_host[: n * h * w].numpy().reshape(n, h, w).copy()
+        cnts = cnt_host[:n].numpy().copy()
+        for j, (k, gi) in enumerate(members):
+            done.append(pool.submit(finish, k, gi, labs[j], int(cnts[j, 1]), int(cnts[j, 2])))
+
+    # the GPU loop runs in this thread next to up to 32 busy pool threads: a short switch interval keeps it
+    # from waiting 5 ms for the interpreter lock at every step (restored below)
+    import sys
+    switch = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
+    windows = [list(range(a, min(a + window, len(mine)))) for a in range(0, len(mine), window)]
+    futs = {k: pool.submit(prepare, mine[k]) for k in (windows[0] if windows else [])}
+    t_loop = time.perf_counter()
+    for wi, win in enumerate(windows):
+        if wi + 1 < len(windows):                    # the pool starts on the next window before the GPU gets this one
+            for k in windows[wi + 1]:
+                futs[k] = pool.submit(prepare, mine[k])
+        t0 = clock()
+        frames = {k: futs.pop(k).result() for k in win}
+        prof["main.wait_for_frames"] += clock() - t0
+        groups = defaultdict(list)
+        for k in win:
+            groups[frames[k].shape].append(k)
+        for shape, ks in sorted(groups.items()):
+            shape_count[shape] += len(ks)
+            for a in range(0, len(ks), batch):
+                part = ks[a:a + batch]
+                n, (h, w) = len(part), shape[:2]
+                t0 = clock()
+                st = stage[n_batches & 1]                 # pinned staging pair: frames are packed while the GPU runs the batch before
+                if st["buf"] is None or st["buf"].numel() < n * h * w * 3:
+                    st["buf"] = torch.empty(max(n, batch) * h * w * 3, dtype=torch.uint8).pin_memory()
+                st["ev"].synchronize()                    # the copy that last read this buffer has finished
+                xb = st["buf"][: n * h * w * 3].view(n, h, w, 3)
+                xnp = xb.numpy()
+                for j, k in enumerate(part):
+                    xnp[j] = frames[k]
+                x = xb.to(dev, non_blocking=True)         # uint8 NHWC; normalised on the device
+                st["ev"].record()
+                t1 = clock()
+                key = (n, h, w)
+                if key not in tuned and n == batch and shape_count[shape] >= 2 * batch:
+                    model.autotune(x)                # once per distinct full-batch shape (the context keeps it)
+                    tuned.add(key)
+                labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes, labels_dtype=torch.uint8,
+                                                      small_zones=small_zones)   # models.py:269-276 on the device
+                slot = n_batches & 1
+                need = n * h * w
+                if ring[slot] is None or ring[slot][0].numel() < need or ring[slot][1].shape[0] < n:
+                    ring[slot] = (torch.empty(max(need, batch * h * w), dtype=torch.uint8).pin_memory(),
+                                  torch.empty((max(n, batch), 3), dtype=torch.int64).pin_memory())
+                ring[slot][0][:need].copy_(labels.reshape(-1), non_blocking=True)
+                ring[slot][1][:n].copy_(counts, non_blocking=True)
+                ring_ev[slot].record()
+                t2 = clock()
+                if pending is not None:
+                    consume(pending)                 # the previous batch's labels, while this one runs
+                prof["main.pack_and_h2d"] += t1 - t0; prof["main.launch"] += t2 - t1; prof["main.consume"] += clock() - t2
+                pending = (slot, [(k, mine[k]) for k in part], n, h, w)
+                n_batches += 1
+        frames.clear()
+    if pending is not None:
+        consume(pending)
+    for f in done:
+        f.result()
+    pool.shutdown()
+    sys.setswitchinterval(switch)
+    torch.cuda.synchronize()
+    t_done = time.perf_counter()
+
+    if os.environ.get("NBC_FOLDER_PROFILE"):
+        print("rank %d stage seconds (pool stages summed over %d threads): %s; loop wall %.2f s" %
+              (rank, workers, ", ".join("%s %.2f" % kv for kv in sorted(prof.items())), t_done - t_loop), flush=True)
+    cap = max(len(s) for s in shards) if shards else 0
+    allrows = gather_rows(rows, n_total, world, dist, dev, cap=cap)
     if rank == 0:
         write_stats_csv(os.path.join(root, "results", "final_stats.csv"),
-                        [stats_row(images[int(r[0])][1], images[int(r[0])][2], int(r[1]), int(r[2]), int(r[3]), int(r[4]))
+                        [stats_row(items[int(r[0])]["name"], items[int(r[0])]["wood"], int(r[1]), int(r[2]), int(r[3]), int(r[4]))
                          for r in allrows])
     if dist is not None:
         dist.barrier()
+    t_end = time.perf_counter()
+    return {"rank": rank, "world": world, "images_total": n_total, "images_this_rank": len(mine), "batches": n_batches,
+            "batch": batch, "host_workers": workers, "setup_s": t_ready - t_start, "loop_s": t_done - t_loop,
+            "total_s": t_end - t_start, "images_per_s_loop": len(mine) / max(t_done - t_loop, 1e-9),
+            "distinct_shapes": len(shape_count), "autotuned_shapes": len(tuned)}
+
+
+def launch_ranks(n: int, argv: Sequence[str]) -> int:
+    """``--gpus N`` without a torchrun environment: start N ranks (one per GPU) as a child process."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < n:                # counts devices without initialising HIP
+        print("predict: --gpus %d but this node shows %d GPU(s)" % (n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "neuralbarkcalculator_amd.predict"] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main(argv=None):
+    import sys
     ap = argparse.ArgumentParser(description="MI355X folder prediction (mirrors bark_calculator/predict.py)")
     ap.add_argument("root_path", metavar="DIR")
     ap.add_argument("--device", default="cuda:0", help="cuda:N (the CPU path is the reference itself)")
@@ -304,18 +556,26 @@ def main(argv=None):
     ap.add_argument("--model_path", default="./best_model.pt")       # predict.py:57
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
     ap.add_argument("--no_small_zones", action="store_true")
-    args = ap.parse_args(argv)
+    ap.add_argument("--gpus", type=int, default=1, help="shard the folder over N GPUs of this node (one process each, RCCL)")
+    ap.add_argument("--batch", type=int, default=None, help="frames of equal size per forward (default 2 in fp32, 8 in bf16)")
+    raw = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(raw)
     if args.only_preprocess:
         generate_folders(args.root_path, True)
         preprocess_images(args.root_path)
         return
     if not args.device.startswith("cuda"):
         raise SystemExit("this package is the MI355X path; run the reference for --device=cpu")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, raw))
     idx = None
     if "WORLD_SIZE" not in os.environ and ":" in args.device:
         idx = int(args.device.split(":")[1])
-    predict_folder(args.root_path, args.model_path, args.precision, args.exclude_nodes,
-                   not args.no_small_zones, idx)
+    stats = predict_folder(args.root_path, args.model_path, args.precision, args.exclude_nodes,
+                           not args.no_small_zones, idx, batch=args.batch)
+    if stats["rank"] == 0:
+        print("predicted %(images_total)d images (%(images_this_rank)d on rank 0, %(batches)d batches): %(total_s).2f s, "
+              "%(images_per_s_loop).1f images/s in the loop on this rank" % stats)
 
 
 if __name__ == "__main__":

@@ -31,6 +31,7 @@ def trim_black(image):                                 # models.py:157-166
 
 
 def reference_preprocess(img_u8, target):
+    """Returns (what imread gives back from the saved file, the float32 image handed to imsave)."""
     image = (img_u8.astype(np.float32) / np.float32(255))           # ToTensor, then .numpy().transpose(1,2,0)
     if max(image.shape) > target:
         image = resize(image, (target, target), order=3, mode='reflect', anti_aliasing=False)
@@ -39,7 +40,7 @@ def reference_preprocess(img_u8, target):
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "x.png")
         imsave(p, image)
-        return imread(p)
+        return imread(p), np.ascontiguousarray(image)
 
 
 def main():
@@ -55,10 +56,18 @@ def main():
     d = rng.randint(30, 256, (64, 64, 3)).astype(np.uint8)
     d[-7:, ::2] = 0                                    # 50 % dark pixels in the last rows: trimmed
     cases["sq64_trim_only"] = (d, 64)
+    e = rng.randint(0, 256, (133, 177, 3)).astype(np.uint8)   # non-integer zoom factors 2.66 x 3.54: the sample
+    cases["rect133x177_to50"] = (e, 50)                # coordinates themselves are rounded float32 products
+    f = rng.randint(0, 256, (61, 53, 3)).astype(np.uint8)
+    f[:9] //= 16                                       # dark (not black) band: the clip range matters, nothing is trimmed
+    cases["rect61x53_to48"] = (f, 48)                  # factors 1.27 x 1.10, like a 1300 x 1100 scan going to 1024
     for name, (img, t) in cases.items():
-        out = reference_preprocess(img, t)
-        np.savez_compressed(os.path.join(OUT, f"preprocess_{name}.npz"), image=img, target=np.asarray(t), expected=out)
-        print(name, img.shape, "->", out.shape, out.dtype)
+        out, pre = reference_preprocess(img, t)
+        # `float32` = the image right before imsave's float -> uint8 conversion: lets the restatement be
+        # compared value for value, in front of the quantisation
+        np.savez_compressed(os.path.join(OUT, f"preprocess_{name}.npz"), image=img, target=np.asarray(t), expected=out,
+                            float32=pre.astype(np.float32))
+        print(name, img.shape, "->", out.shape, out.dtype, pre.dtype)
 
 
 if __name__ == "__main__":

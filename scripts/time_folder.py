@@ -1,29 +1,50 @@
 #!/usr/bin/env python3
-"""End-to-end folder prediction (next rows N1-N3): decode, forward, remove_small_zones, label PNG, CSV.
-usage: python scripts/time_folder.py [n_images] ; NBC_HOST_WORKERS sets the host thread pool (default 8, max 32)."""
-import os, sys, time, tempfile, shutil
+"""End-to-end folder prediction on one GPU (BASELINE.json configs[3] per rank; next rows N1-N3): a synthetic
+folder of 1024x1024 .bmp samples -> decode, preprocess, processed/ PNG, forward + remove_small_zones, label
+PNG, CSV.  usage: python scripts/time_folder.py [n_images=1000] [precisions=bf16,fp32]
+NBC_HOST_WORKERS sets the host thread pool (default 16, the GPU box's CPU share per GPU)."""
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np, torch
+import numpy as np
+import torch
+from concurrent.futures import ThreadPoolExecutor
 from PIL import Image
 from neuralbarkcalculator_amd import predict as drv, synth
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+precisions = (sys.argv[2] if len(sys.argv) > 2 else "bf16,fp32").split(",")
+distinct = min(n, 40)
 root = tempfile.mkdtemp(prefix="nbc_folder_")
 try:
-    for wood in ("epinette_gelee", "sapin"):
+    t0 = time.perf_counter()
+    woods = ("epinette_gelee", "epinette_non_gelee", "sapin")
+    for wood in woods:
         os.makedirs(os.path.join(root, "samples", wood))
-    for i in range(n):
-        Image.fromarray(synth.make_frame(i, 1024, 1024), mode="RGB").save(
-            os.path.join(root, "samples", ("epinette_gelee", "sapin")[i % 2], "f%04d.png" % i))
+    with ThreadPoolExecutor(16) as pool:
+        frames = list(pool.map(lambda i: synth.make_frame(i, 1024, 1024), range(distinct)))
+        list(pool.map(lambda i: Image.fromarray(frames[i % distinct], mode="RGB").save(
+            os.path.join(root, "samples", woods[i % 3], "f%04d.bmp" % i)), range(n)))
     ckpt = os.path.join(root, "best_model.pt")
     torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict("trained_like", seed=7).items()}, ckpt)
-    for workers in (1, 8, 16):
-        os.environ["NBC_HOST_WORKERS"] = str(workers)
-        shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
-        t0 = time.perf_counter()
-        drv.predict_folder(root, ckpt, precision="bf16", device_index=0)
-        dt = time.perf_counter() - t0
-        print(f"{n} images of 1024x1024, {workers} host workers: {dt:.2f} s end to end = {n / dt:.1f} images/s "
-              f"(includes folder set-up, preprocessing copies, weight packing and upload)", flush=True)
+    print(f"folder of {n} synthetic 1024x1024 .bmp samples ({distinct} distinct frames) made in {time.perf_counter() - t0:.1f} s; "
+          f"host workers {drv._host_workers()}, cores available {len(os.sched_getaffinity(0))}", flush=True)
+    for prec in precisions:
+        for rep in range(2):                  # second run: page cache and allocator warm
+            shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
+            shutil.rmtree(os.path.join(root, "processed"), ignore_errors=True)
+            t0 = time.perf_counter()
+            st = drv.predict_folder(root, ckpt, precision=prec, device_index=0)
+            dt = time.perf_counter() - t0
+            rows = open(os.path.join(root, "results", "final_stats.csv")).read().count("\n") - 1
+            print(f"{prec} run {rep}: {n} images end to end in {dt:.2f} s = {n / dt:.1f} images/s "
+                  f"(checkpoint load + weight packing + upload {st['setup_s']:.2f} s included); steady loop {st['images_per_s_loop']:.1f} "
+                  f"images/s; CSV rows {rows}; {json.dumps({k: st[k] for k in ('batch', 'batches', 'distinct_shapes', 'autotuned_shapes', 'host_workers')})}",
+                  flush=True)
 finally:
     shutil.rmtree(root, ignore_errors=True)

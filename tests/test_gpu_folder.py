@@ -63,3 +63,63 @@ def test_predict_folder_matches_oracle(tmp_path, oracle_model, sd_np, built_lib,
     # fp32 parity mode: label PNGs are bit-identical except where a logit tie flips a pixel (rare;
     # remove_small_zones can enlarge such a flip to a zone of < 150 px)
     assert total_flips <= 150, total_flips
+
+
+def _make_folder(root, sd_np, layout):
+    frames = {}
+    for wood, name, idx, h, w in layout:
+        d = os.path.join(root, "samples", wood)
+        os.makedirs(d, exist_ok=True)
+        img = synth.make_frame(idx, h, w)
+        Image.fromarray(img, mode="RGB").save(os.path.join(d, name))
+        frames[(wood, name.replace("bmp", "png"))] = img
+    ckpt = os.path.join(root, "best_model.pt")
+    torch.save({k: torch.from_numpy(v) for k, v in sd_np.items()}, ckpt)
+    return ckpt, frames
+
+
+def test_batched_folder_equals_one_by_one(tmp_path, sd_np, built_lib):
+    """Equal-sized frames ride in batches (and the label PNGs come back through the pinned double buffer): every
+    file and the CSV must be what batch = 1 writes.  Two windows, three shapes, a ragged last batch."""
+    layout = [("sapin", "s%02d.bmp" % i, 40 + i, 128 if i % 5 else 96, 192) for i in range(11)] + \
+             [("epinette_gelee", "e%02d.png" % i, 60 + i, 160, 160) for i in range(5)]
+    outs = []
+    for batch in (1, 4):
+        root = str(tmp_path / ("b%d" % batch))
+        ckpt, _ = _make_folder(root, sd_np, layout)
+        st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0, batch=batch, window=8)
+        assert st["images_total"] == 16 and st["images_this_rank"] == 16
+        files = {}
+        for wood in ("sapin", "epinette_gelee"):
+            for n in sorted(os.listdir(os.path.join(root, "results", "outputs", wood))):
+                files[(wood, n)] = np.asarray(Image.open(os.path.join(root, "results", "outputs", wood, n)))
+            for n in sorted(os.listdir(os.path.join(root, "processed", "samples", wood))):
+                files[("processed", wood, n)] = np.asarray(Image.open(os.path.join(root, "processed", "samples", wood, n)))
+        outs.append((files, open(os.path.join(root, "results", "final_stats.csv")).read()))
+    assert outs[0][1] == outs[1][1]
+    assert outs[0][0].keys() == outs[1][0].keys() and len(outs[0][0]) == 32
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL broadcast + all_gather with two ranks)")
+def test_two_rank_folder_over_rccl(tmp_path, sd_np, built_lib):
+    """`python -m neuralbarkcalculator_amd.predict DIR --gpus 2`: the ranks start themselves, rank 0 alone reads the
+    checkpoint, the packed weights travel by RCCL broadcast, the rows by all_gather; same files as one GPU."""
+    import subprocess
+    import sys
+    layout = [("sapin", "s%02d.bmp" % i, 40 + i, 128 + 8 * (i % 3), 192) for i in range(9)]
+    outs = []
+    for gpus in (1, 2):
+        root = str(tmp_path / ("g%d" % gpus))
+        ckpt, _ = _make_folder(root, sd_np, layout)
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", root, "--model_path", ckpt, "--gpus", str(gpus)],
+                           cwd=repo, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        labs = [np.asarray(Image.open(os.path.join(root, "results", "outputs", "sapin", n)))
+                for n in sorted(os.listdir(os.path.join(root, "results", "outputs", "sapin")))]
+        outs.append((labs, open(os.path.join(root, "results", "final_stats.csv")).read()))
+    assert outs[0][1] == outs[1][1] and len(outs[0][0]) == 9
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)

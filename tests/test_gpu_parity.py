@@ -397,3 +397,79 @@ def test_fp32_against_the_numpy_restatement(gpu_fp32, sd_np):
     top2 = np.sort(logits, axis=0)
     clear = (top2[2] - top2[1]) > 1e-4 * scale
     assert np.array_equal(labels[0].cpu().numpy()[clear], labels_np[clear])
+
+
+def test_plan_cache_keeps_each_shapes_tiles(gpu_bf16):
+    """The context keeps the launch plan (and its measured tiles) of every shape it has seen: a folder that
+    alternates between trimmed heights tunes each (N,H,W) once; installing tiles by hand works the same way."""
+    a = frames([70], 136, 200).to(DEV)
+    b = frames([71, 72], 96, 160).to(DEV)
+    try:
+        ta = gpu_bf16.autotune(a)
+        ra = gpu_bf16.lowres_logits(a)
+        gpu_bf16.lowres_logits(b)                              # another plan in between
+        tb = gpu_bf16.plan_tiles()
+        custom = [7 if t != 7 else 0 for t in tb]              # 128x64 tiles fit every layer (Cout % 64 == 0)
+        gpu_bf16.set_plan_tiles(custom)
+        rb = gpu_bf16.lowres_logits(b)
+        assert gpu_bf16.plan_tiles() == custom
+        assert torch.equal(gpu_bf16.lowres_logits(a), ra) and gpu_bf16.plan_tiles() == ta      # shape A came back with its tiles
+        assert torch.equal(gpu_bf16.lowres_logits(b), rb) and gpu_bf16.plan_tiles() == custom
+        with pytest.raises(RuntimeError):
+            gpu_bf16.set_plan_tiles(custom[:-1])
+        with pytest.raises(RuntimeError):
+            gpu_bf16.set_plan_tiles([5] * len(custom))         # 128x256 does not divide Cout = 64
+    finally:
+        gpu_bf16.set_conv_impl(1, -1)
+
+
+def test_fp32_has_no_256x256_tile(gpu_fp32):
+    """Tile 3 needs 2 x 128 accumulator registers in the two-level f32 kernel: forcing it falls back to the plan's tile."""
+    x = frames([73], 64, 72).to(DEV)
+    base = gpu_fp32.lowres_logits(x)
+    tiles = gpu_fp32.plan_tiles()
+    assert 3 not in tiles
+    try:
+        gpu_fp32.set_conv_impl(1, 3)
+        assert torch.equal(gpu_fp32.lowres_logits(x), base)
+        with pytest.raises(RuntimeError):
+            gpu_fp32.set_plan_tiles([3 if i > 40 else t for i, t in enumerate(tiles)])
+    finally:
+        gpu_fp32.set_conv_impl(1, -1)
+
+
+def test_bcast_weights_at_the_c_abi(built_lib, sd_np):
+    """nbc_bcast_weights (include/nbc.h) with a real RCCL communicator of the host process: one rank here (a
+    one-GPU box), which exercises the symbol lookup, the communicator query and the root path; the non-root
+    path (allocate, receive, attach) needs a second GPU: tests/test_gpu_folder.py::test_two_rank_folder_over_rccl
+    covers the same broadcast through torch.distributed."""
+    import ctypes as C
+    from neuralbarkcalculator_amd import _lib
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if not os.path.exists(path):
+        pytest.skip("torch ships no librccl.so here")
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        m = FCNResNet50("bf16").load_state_dict(sd_np).to(DEV)
+        x = frames([74], 64, 64).to(DEV)
+        want = m.lowres_logits(x)
+        stream = torch.cuda.current_stream().cuda_stream
+        lib = _lib.load()
+        _lib.check(lib.nbc_bcast_weights(m._ctx, comm, 0, _lib.PREC_BF16, stream), "nbc_bcast_weights")
+        torch.cuda.synchronize()
+        assert torch.equal(m.lowres_logits(x), want)
+        assert lib.nbc_bcast_weights(m._ctx, comm, 0, _lib.PREC_FP32, stream) == _lib.NBC_ERR_STATE     # root holds bf16 weights
+        assert lib.nbc_bcast_weights(m._ctx, None, 0, _lib.PREC_BF16, stream) == _lib.NBC_ERR_INVALID
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)

@@ -1,5 +1,5 @@
 """The preprocessor's resize on the GPU (nbc_resize_cubic_u8, models.py:191-198) against the numpy
-restatement (bit for bit) and the scikit-image 0.18.3 fixtures (same tolerance as the CPU test)."""
+restatement and the scikit-image 0.18.3 fixtures, bit for bit."""
 import glob
 import os
 
@@ -54,5 +54,21 @@ def test_skimage_fixtures_through_the_device(model, path):
     g = np.load(path, allow_pickle=False)
     out = drv.preprocess_image(g["image"], int(g["target"]), model)
     assert out.shape == g["expected"].shape and out.dtype == np.uint8
-    diff = np.abs(out.astype(np.int16) - g["expected"].astype(np.int16))
-    assert diff.max() <= 1 and (diff > 0).mean() < 2e-2        # exact x.5 ties only, as in tests/test_driver.py
+    assert np.array_equal(out, g["expected"])                   # byte for byte what scikit-image 0.18.3 saved
+
+
+def test_device_quantisation_and_lit_counts(model):
+    """nbc_preprocess_u8: the bytes imsave would write and trim_black's per-row lit counts, from the device."""
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, size=(1300, 1100, 3), dtype=np.uint8)
+    img[:150] = 0                                                # black rows
+    img[150:300, ::3] = 0                                        # a third of the pixels black
+    img[700, :, :2] = 0                                          # two channels out: still lit
+    f = drv.resize_bicubic_reflect(img.astype(np.float32) / np.float32(255), 512, 512)
+    out, lit = model.preprocess_u8(torch.from_numpy(img).to(DEV), 512, 512)
+    assert np.array_equal(out.cpu().numpy(), drv._float_to_u8(f))
+    assert np.array_equal(lit.cpu().numpy(), (np.sum(f, axis=-1) > 1e-3).sum(axis=1))
+    # and the whole preprocessor: device route == numpy route, trimmed rows included
+    a = drv.preprocess_image(img[:, :1100][:1100], 512)
+    b = drv.preprocess_image(img[:, :1100][:1100], 512, model)
+    assert a.shape == b.shape and a.shape[0] < 512 and np.array_equal(a, b)

@@ -134,3 +134,14 @@ def test_predict_labels_with_small_zones(model):
     assert got_x.dtype == torch.int64
     np.testing.assert_array_equal(got_x.cpu().numpy(), want_x)
     assert counts_x.tolist() == [[int((want_x == c).sum()) for c in range(3)]]
+
+
+def test_batches_beyond_85_maps(model):
+    """The counters are finished by a grid-stride launch: any batch size works (it used to stop at 85)."""
+    rng = np.random.default_rng(17)
+    labs = (rng.random((100, 48, 80)) < 0.45).astype(np.uint8) * rng.integers(1, 3, size=(100, 48, 80)).astype(np.uint8)
+    out, counts = run_gpu(model, labs, min_pixels=12)
+    for b in range(100):
+        want = remove_small_zones(labs[b], 12)
+        np.testing.assert_array_equal(out[b], want)
+        assert counts[b].tolist() == [int((want == c).sum()) for c in range(3)]
