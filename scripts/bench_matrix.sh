@@ -1,12 +1,16 @@
 #!/bin/bash
-# A/B matrix of bench.py configurations on one GPU box (writes gpurun_out/<tag>.json).
-set -e
-mkdir -p gpurun_out
-run() { tag=$1; shift; timeout -k 10 240 python bench.py --no-cpu-baseline --no-parity "$@" --dump-ops gpurun_out/ops_$tag.json > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; python - <<PY
-import json
-d=json.load(open("gpurun_out/bench_$tag.json"))
-r=d.get("roofline",{})
-print("$tag", "img/s %.1f" % d["value"], "ms/step %.3f" % d["ms_per_step"], "instr %.3f" % r.get("instrumented_ms_per_step",0), "conv TF %.0f" % r.get("achieved",0), "3x3 TF %.0f" % r.get("conv3x3_tflops",0), "sumk %.3f" % r.get("sum_kernel_ms_per_step",0))
+# One-line summaries of several bench.py configurations on ONE box (A/B runs must share a box: +-4 % between boxes).
+#   gpurun -- 'bash scripts/bench_matrix.sh "<flags 1>" "<flags 2>" ...'   ->  gpurun_out/matrix/
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/matrix; mkdir -p $out
+i=0
+for flags in "$@"; do
+  i=$((i+1))
+  timeout -k 10 300 python $root/bench.py --no-cpu-baseline --no-parity $flags > $out/run$i.json 2> $out/run$i.err || { echo "run $i failed"; tail -3 $out/run$i.err; continue; }
+  python3 - "$out/run$i.json" "$flags" <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1])); r=d.get("roofline",{}); b=d.get("bf16_batch8")
+print("%-50s %8.1f img/s  %6.2f ms/step  frac %.3f  3x3 %.1f TF" % (sys.argv[2], d["value"], d["ms_per_step"], r.get("frac",0), r.get("conv3x3_tflops",0)),
+      ("| b8 %.1f img/s frac %.3f" % (b["value"], b.get("roofline",{}).get("frac",0))) if b else "")
 PY
-}
-"$@"
+done

@@ -25,7 +25,7 @@ from neuralbarkcalculator_amd.model import FCNResNet50
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_RTOL_FP32 = 2e-5
+LOGIT_RTOL_FP32 = 5e-6      # against float64: measured 1.5e-6 .. 2.3e-6 of the logit range (CPU f32 oracle: 1.2e-6 .. 1.8e-6)
 LOGIT_RTOL_BF16 = 4e-2
 BF16_MARGIN_BAND = 0.10
 DEV = "cuda:0"

@@ -60,9 +60,10 @@ def test_predict_folder_matches_oracle(tmp_path, oracle_model, sd_np, built_lib,
             assert row == drv.stats_row(name, wood, lab.shape[0], lab.shape[1], int((lab == 1).sum()), int((lab == 2).sum()))
         if exclude_nodes:
             assert 255 not in np.unique(got) and row[4] == "0.00000"
-    # fp32 parity mode: label PNGs are bit-identical except where a logit tie flips a pixel (rare;
-    # remove_small_zones can enlarge such a flip to a zone of < 150 px)
-    assert total_flips <= 150, total_flips
+    # fp32 parity mode: label PNGs are bit-identical except where an exact logit tie flips a pixel (0-2 per
+    # 1024x1024 frame, see test_gpu_configs.py) -- none in these eight small frames
+    print("folder label PNG bytes differing from the oracle's over 8 images:", total_flips)
+    assert total_flips <= 4, total_flips
 
 
 def _make_folder(root, sd_np, layout):

@@ -3,8 +3,9 @@ oracle on the same seeded inputs and against the committed goldens.
 
 Tolerances (stated here, used below):
   * fp32 mode ("parity mode", v_mfma_f32_32x32x2_f32): every conv unit's output and the final
-    logits agree with the oracle to LOGIT_RTOL_FP32 of the tensor's max magnitude (the two sides
-    sum the same f32 products in different orders; oneDNN's blocked order cannot be reproduced).
+    logits agree with the oracle to LAYER_/LOGIT_RTOL_FP32 of the tensor's max magnitude (the two sides
+    sum the same f32 products in different blocked orders; oneDNN's cannot be reproduced; both sit
+    2e-6 of the logit range from a float64 evaluation).
     Labels are integers and must be IDENTICAL wherever the oracle's top-2 logit margin exceeds
     twice the measured logit error; pixels inside that band are exact ties up to f32 rounding and
     are counted and bounded (MAX_TIE_FLIPS_FRAC).
@@ -23,11 +24,11 @@ from neuralbarkcalculator_amd.model import FCNResNet50
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_RTOL_FP32 = 2e-5
-LAYER_RTOL_FP32 = 2e-5
+LOGIT_RTOL_FP32 = 5e-6      # measured 1.6e-6 .. 3.3e-6 (two-level f32 sums; the CPU side differs from float64 by 1.8e-6 itself)
+LAYER_RTOL_FP32 = 4e-6      # measured worst layer 1.5e-6
 LOGIT_RTOL_BF16 = 4e-2
 LAYER_RTOL_BF16 = 4e-2
-MAX_TIE_FLIPS_FRAC = 2e-5
+MAX_TIE_FLIPS_FRAC = 4e-6    # of the pixels: 4 of 1 048 576 (measured 0-2, adjudicated by float64 in test_gpu_configs.py)
 BF16_MARGIN_BAND = 0.10
 
 DEV = "cuda:0"
@@ -254,11 +255,13 @@ def test_errors_are_python_exceptions(gpu_fp32):
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, impl, tile):
     """Each conv kernel instantiation (register-staged v1; LDS-DMA v2 at every tile shape) against
-    the oracle, layer by layer, on an input whose height is not a multiple of the tile rows."""
+    the oracle, layer by layer, on two images whose height is not a multiple of the tile rows."""
     from oracle.fcn_resnet50_oracle import layer_outputs
     model = gpu_fp32 if mode == "fp32" else gpu_bf16
     rtol = LAYER_RTOL_FP32 if mode == "fp32" else LAYER_RTOL_BF16
-    x = frames([9], 104, 136)
+    if mode == "fp32" and impl == 0:
+        rtol = 2e-5          # the register-staged kernel sums each output in ONE f32 chain (up to 18 432 terms): measured 6e-6
+    x = frames([9, 10], 104, 136)
     ref = layer_outputs(oracle_model, x)
     model.set_conv_impl(impl, tile)
     model.set_keep_activations(True)
@@ -344,7 +347,7 @@ def test_ragged_shapes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, shape):
     x = frames(range(30, 30 + n), h, w)
     labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
     scale = float(lowres_ref.abs().max())
-    for model, rtol, min_agree in ((gpu_fp32, LOGIT_RTOL_FP32, 0.9995), (gpu_bf16, LOGIT_RTOL_BF16, 0.97)):
+    for model, rtol, min_agree in ((gpu_fp32, LOGIT_RTOL_FP32, 0.9999), (gpu_bf16, LOGIT_RTOL_BF16, 0.97)):
         labels, counts, lowres = model.predict_labels(x.to(DEV), return_lowres=True)
         assert tuple(labels.shape) == (n, h, w) and tuple(lowres.shape) == tuple(lowres_ref.shape)
         err = float((lowres.cpu() - lowres_ref).abs().max())
