@@ -156,11 +156,20 @@ def main():
             local_rank = 0
             args.dist_backend = "gloo"
         torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
-        dist.barrier()
+        # stdout carries rank 0's ONE JSON line and nothing else: whatever the communication libraries print
+        # while they connect (gloo announces its peers on stdout) goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.dist_backend)
+            dist.barrier()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         setup["process_group_init_s"] = time.perf_counter() - t0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -13,7 +13,7 @@ out=$root/gpurun_out/profile_round
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 K=${K:-12}; W=${W:-3}
-python3 $root/bench.py --steps $K --warmup $W --bf16-steps $K --bf16-streams 1 --no-cpu-baseline --no-parity --save-tiles $out/tiles.json > $out/bench_tiles.json 2> $out/bench_tiles.err
+python3 $root/bench.py --streams 1 --steps $K --warmup $W --bf16-steps $K --bf16-streams 1 --no-cpu-baseline --no-parity --save-tiles $out/tiles.json > $out/bench_tiles.json 2> $out/bench_tiles.err
 for cfg in "fp32 1 f32" "bf16 8 bf16"; do
   set -- $cfg; prec=$1; batch=$2; dt=$3
   d=$out/${dt}_b${batch}; mkdir -p $d

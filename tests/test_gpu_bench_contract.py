@@ -17,8 +17,8 @@ def run_bench(*flags, timeout=900):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]      # ONE line on stdout, the JSON object
     return json.loads(lines[0])
 
 
