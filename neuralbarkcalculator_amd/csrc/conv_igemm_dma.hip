@@ -3,11 +3,13 @@
 // Same GEMM view, K-step (128 bytes of K per row), LDS image (XOR-swizzled 16-byte chunks) and
 // fused BN(+residual)(+ReLU) epilogue as conv_igemm.hip; what changes is how tiles reach LDS:
 //
-//   * global_load_lds_dwordx4 (LDS-DMA): each lane names a 16-byte SOURCE (a pixel's channel
-//     chunk, a weight-row chunk, or the zero page for padding-halo / tail lanes); the wave's 64
-//     chunks land in 1 KiB of LDS contiguously (8 rows x 128 B).  The swizzle therefore sits on
-//     the source side: physical slot p of row r holds logical chunk p ^ ((r>>1)&7)
-//     (cdna_hip_programming.md rule 21).  No staging VGPRs, no ds_write.
+//   * LDS-DMA (buffer_load_dwordx4 ... lds through a buffer resource over the activation / weight
+//     buffer): each lane names a 16-byte SOURCE by a 32-bit offset (a pixel's channel chunk, a
+//     weight-row chunk, or an offset outside the resource for padding-halo / tail lanes, which the
+//     hardware's range check turns into zeros); the wave's 64 chunks land in 1 KiB of LDS
+//     contiguously (8 rows x 128 B).  The swizzle therefore sits on the source side: physical slot
+//     p of row r holds logical chunk p ^ ((r>>1)&7) (cdna_hip_programming.md rule 21).  No staging
+//     VGPRs, no ds_write; the K-step's advance is the instruction's scalar offset.
 //   * an S-stage LDS ring with COUNTED s_waitcnt vmcnt(N) and a raw s_barrier, one barrier per
 //     K-step: at the top of step t a wave waits until only the (S-2) youngest K-steps' DMAs are
 //     outstanding (its share of step t has landed), the barrier makes every wave's share visible
@@ -57,6 +59,24 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
+// The same through a buffer resource: 64 lanes x 16 bytes from `rsrc` base + per-lane 32-bit offset + a
+// wave-uniform scalar offset.  Three instructions per DMA instead of seven (no 64-bit pointer per row to
+// advance, no M0 save/restore): every instruction a SIMD issues beside its MFMAs costs the matrix pipe
+// about its own issue time (tools/mfma_f32_probe.hip).  A lane whose offset lies outside the resource
+// (halo and tail lanes: kOutOfRange) gets zeros from the hardware's range check: no zero page.
+// M0 is written and left: nothing else in this kernel reads it (the scale/shift DMAs above restore it).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned kOutOfRange = 0x80000000u;      // >= every resource size (activations and weights stay below 2 GiB)
+__device__ __forceinline__ void dma16_buf(unsigned voff, rsrc_t rsrc, unsigned lds_base, unsigned soff) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, %3 offen lds"
+      :
+      : "v"(voff), "s"(rsrc), "s"(lds_base), "s"(soff)
       : "memory");
 }
 
@@ -136,11 +156,10 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   // Wave w's 64 lanes cover rows 8w..8w+7 of a pass = 1 KiB of LDS, linear in the lane.
   const int ps = tid & 7;
   const int lr = tid >> 3;
-  const unsigned char* xb = static_cast<const unsigned char*>(p.x);
-  const unsigned char* wb = static_cast<const unsigned char*>(p.w);
-  const unsigned char* zpage = static_cast<const unsigned char*>(p.zero);
+  const rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+  const rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
   const int pix_bytes = p.Ci * EB;
-  const size_t wrow_bytes = (size_t)p.ksteps * 128;
+  const unsigned wrow_bytes = (unsigned)p.ksteps * 128u;
 
   int a_iy0[A_PASSES], a_ix0[A_PASSES], a_img[A_PASSES], a_coff[A_PASSES];
   {
@@ -167,11 +186,11 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
       }
     }
   }
-  const unsigned char* wsrc[B_PASSES];       // advances by one K-step (128 B) per issue
+  unsigned w_off[B_PASSES];                  // byte offset of the row's chunk in K-step 0; K-step t adds the scalar t * 128
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
     const int row = lr + ROWS_PER_PASS * i;
-    wsrc[i] = wb + (size_t)(n0 + row) * wrow_bytes + (ps ^ ((row >> 1) & 7)) * 16;
+    w_off[i] = (unsigned)(n0 + row) * wrow_bytes + (unsigned)(ps ^ ((row >> 1) & 7)) * 16u;
   }
 
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
@@ -185,21 +204,19 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
     while (st_kw >= p.KW) { st_kw -= p.KW; ++st_kh; }
   }
 
-  // Source pointers of the activation rows for the CURRENT tap.  Inside a tap a K-step only moves
-  // 128 bytes along the channels, so the per-step work is one pointer add per row; the bounds test
-  // and the address arithmetic run once per tap (once per kernel for a 1x1 convolution).  Halo and
-  // tail rows point at the zero page and do not advance.
-  const unsigned char* a_ptr[A_PASSES];
-  int a_inc[A_PASSES];
+  // Byte offsets of the activation rows for the CURRENT tap (channel block 0).  Inside a tap a K-step only
+  // moves 128 bytes along the channels: that is the DMA's scalar offset (ld_cb * 128), so a K-step costs no
+  // vector instruction per row; the bounds test and the address arithmetic run once per tap (once per
+  // kernel for a 1x1 convolution).  Halo and tail rows carry an offset outside the resource: zeros.
+  unsigned a_off[A_PASSES];
   auto set_tap = [&](int kh, int kw) __attribute__((always_inline)) {
     const int dy = kh * p.dil, dx = kw * p.dil;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
       const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * pix_bytes + a_coff[i];
-      a_ptr[i] = ok ? xb + off : zpage;
-      a_inc[i] = ok ? 128 : 0;
+      const unsigned off = (unsigned)(a_img[i] + iy * p.Wi + ix) * (unsigned)pix_bytes + (unsigned)a_coff[i];
+      a_off[i] = ok ? off : kOutOfRange;
     }
   };
   if constexpr (!STEM) set_tap(0, 0);
@@ -209,22 +226,19 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
     if (d < A_PASSES) {
       const int i = d;
       if constexpr (!STEM) {
-        dma16(a_ptr[i], sa + (unsigned)(ROWS_PER_PASS * 128 * i));
-        a_ptr[i] += a_inc[i];
+        dma16_buf(a_off[i], xrsrc, sa + (unsigned)(ROWS_PER_PASS * 128 * i), (unsigned)ld_cb * 128u);
       } else {
         // stem: one chunk = one tap's padded pixel; this lane's tap of the K-step being issued is
         // (st_kh, st_kw), advanced by 8 taps per K-step without a division (all passes of a lane
         // share the chunk: ROWS_PER_PASS is a multiple of 16)
         const int iy = a_iy0[i] + st_kh * p.dil, ix = a_ix0[i] + st_kw * p.dil;
         const bool ok = st_kh < p.KH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const long long off = (long long)(a_img[i] + iy * p.Wi + ix) * 16;
-        const unsigned char* src = ok ? xb + off : zpage;
-        dma16(src, sa + (unsigned)(ROWS_PER_PASS * 128 * i));
+        const unsigned off = (unsigned)(a_img[i] + iy * p.Wi + ix) * 16u;
+        dma16_buf(ok ? off : kOutOfRange, xrsrc, sa + (unsigned)(ROWS_PER_PASS * 128 * i), 0u);
       }
     } else {
       const int i = d - A_PASSES;
-      dma16(wsrc[i], sa + (unsigned)(A_BYTES + ROWS_PER_PASS * 128 * i));
-      wsrc[i] += 128;
+      dma16_buf(w_off[i], wrsrc, sa + (unsigned)(A_BYTES + ROWS_PER_PASS * 128 * i), (unsigned)t * 128u);
     }
   };
   // The L DMAs of a K-step are issued in four parts so that the main loop can slot one part behind
@@ -815,7 +829,9 @@ int choose_conv_tile(int M, int Co, int precision) {
 
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s) {
   const int eb = precision == 0 ? 4 : 2;
-  if (a.M <= 0 || a.Co % 64 != 0 || a.ksteps <= 0 || a.zero == nullptr) return hipErrorInvalidValue;
+  if (a.M <= 0 || a.Co % 64 != 0 || a.ksteps <= 0 || a.x_bytes == 0 || a.x_bytes >= kOutOfRange || a.w_bytes == 0 ||
+      a.w_bytes >= kOutOfRange)
+    return hipErrorInvalidValue;
   if (a.stem) {
     if (a.Ci * eb != 16 || a.ksteps * 8 < a.KH * a.KW) return hipErrorInvalidValue;
   } else {

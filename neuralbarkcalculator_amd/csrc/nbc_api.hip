@@ -64,7 +64,6 @@ struct nbc_ctx {
   std::vector<size_t> buf_cap;
   float* lowres = nullptr;
   size_t lowres_cap = 0;
-  void* zero_page = nullptr;                // 256 zero bytes: DMA source of halo / tail lanes
   int conv_impl = 1;                        // 1 = LDS-DMA ring (v2), 0 = register-staged (v1)
   int conv_tile = -1;                       // v2 tile override, -1 = per-layer choice
   bool keep = false;
@@ -256,7 +255,6 @@ int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream
   a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
   a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
   a.y = c->bufs[o.out_buf];
-  a.zero = c->zero_page;
   a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
   a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
   a.KH = u.k; a.KW = u.k; a.stride = u.stride; a.pad = u.pad; a.dil = u.dil;
@@ -306,10 +304,6 @@ int nbc_create(nbc_ctx** out, int hip_device) {
     return set_error(NBC_ERR_HIP, std::string("nbc_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
   nbc_ctx* c = new nbc_ctx();
   c->device = hip_device;
-  if (hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
-    delete c;
-    return set_error(NBC_ERR_NOMEM, "nbc_create: cannot allocate the zero page");
-  }
   *out = c;
   return NBC_OK;
 }
@@ -319,7 +313,6 @@ int nbc_destroy(nbc_ctx* c) {
   (void)hipSetDevice(c->device);
   for (void* b : c->bufs) if (b) (void)hipFree(b);
   if (c->lowres) (void)hipFree(c->lowres);
-  if (c->zero_page) (void)hipFree(c->zero_page);
   if (c->zones_ws) (void)hipFree(c->zones_ws);
   if (c->scratch256) (void)hipFree(c->scratch256);
   if (c->owned_weights) (void)hipFree(c->owned_weights);

@@ -15,8 +15,7 @@ struct ConvArgs {
   const float* shift;   // [Co]
   const void* res;      // nullable, [M][Co] elements (the identity of a bottleneck)
   void* y;              // [M][Co] elements
-  const void* zero;     // >= 16 zero bytes in device memory: DMA source of halo / tail lanes (v2)
-  unsigned x_bytes;     // size of x in bytes (< 2 GiB): buffer range check = zero fill of the halo (v1)
+  unsigned x_bytes;     // size of x in bytes (< 2 GiB): the buffer resource's range check zero-fills halo and tail lanes
   unsigned w_bytes;     // size of w in bytes
   int N, Hi, Wi, Ci;
   int Ho, Wo, Co;

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   const int nblk = ((M + nbc::conv_tile_rows(tile) - 1) / nbc::conv_tile_rows(tile)) * (Co / nbc::conv_tile_cols(tile));
   CK(hipMalloc(&dst, (size_t)nblk * 512)); CK(hipMemset(dst, 0, (size_t)nblk * 512));
   nbc::ConvArgs a{};
-  a.x = dx; a.w = dw; a.scale = ds; a.shift = db; a.res = res ? dr : nullptr; a.y = dy; a.zero = dz;
+  a.x = dx; a.w = dw; a.scale = ds; a.shift = db; a.res = res ? dr : nullptr; a.y = dy;
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.N = 1; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Hi; a.Wo = Wi; a.Co = Co;
   a.KH = a.KW = K; a.stride = 1; a.pad = dil * (K / 2); a.dil = dil; a.M = M; a.ksteps = ksteps; a.relu = 1; a.stem = 0;
   a.wo_shift = -1;
