@@ -237,3 +237,20 @@ def test_fast_bmp_decoder_equals_pil(tmp_path):
     assert drv._decode_bmp24(open(pal, "rb").read()) is None
     assert np.array_equal(drv._decode_rgb(pal), np.asarray(Image.open(pal).convert("RGB")))
     assert drv._decode_bmp24(b"BM" + b"\0" * 10) is None
+
+
+def test_gpus_flag_refuses_more_ranks_than_gpus(tmp_path):
+    """`--gpus N` starts its own ranks only when the node shows N GPUs; asked for more it says so and exits non-zero
+    (no silent one-rank run).  Runs anywhere: counting devices does not initialise HIP."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 3
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "--gpus %d" % n in p.stderr and not p.stdout.strip()
+    _touch_image(os.path.join(str(tmp_path), "samples", "sapin", "a.png"))
+    p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", str(tmp_path), "--gpus", str(n)], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "--gpus %d" % n in p.stderr
