@@ -448,63 +448,65 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     import sys
     switch = sys.getswitchinterval()
     sys.setswitchinterval(2e-4)
-    windows = [list(range(a, min(a + window, len(mine)))) for a in range(0, len(mine), window)]
-    futs = {k: pool.submit(prepare, mine[k]) for k in (windows[0] if windows else [])}
-    t_loop = time.perf_counter()
-    for wi, win in enumerate(windows):
-        if wi + 1 < len(windows):                    # the pool starts on the next window before the GPU gets this one
-            for k in windows[wi + 1]:
-                futs[k] = pool.submit(prepare, mine[k])
-        t0 = clock()
-        frames = {k: futs.pop(k).result() for k in win}
-        prof["main.wait_for_frames"] += clock() - t0
-        groups = defaultdict(list)
-        for k in win:
-            groups[frames[k].shape].append(k)
-        for shape, ks in sorted(groups.items()):
-            shape_count[shape] += len(ks)
-            for a in range(0, len(ks), batch):
-                part = ks[a:a + batch]
-                n, (h, w) = len(part), shape[:2]
-                t0 = clock()
-                st = stage[n_batches & 1]                 # pinned staging pair: frames are packed while the GPU runs the batch before
-                if st["buf"] is None or st["buf"].numel() < n * h * w * 3:
-                    st["buf"] = torch.empty(max(n, batch) * h * w * 3, dtype=torch.uint8).pin_memory()
-                st["ev"].synchronize()                    # the copy that last read this buffer has finished
-                xb = st["buf"][: n * h * w * 3].view(n, h, w, 3)
-                xnp = xb.numpy()
-                for j, k in enumerate(part):
-                    xnp[j] = frames[k]
-                x = xb.to(dev, non_blocking=True)         # uint8 NHWC; normalised on the device
-                st["ev"].record()
-                t1 = clock()
-                key = (n, h, w)
-                if key not in tuned and n == batch and shape_count[shape] >= 2 * batch:
-                    model.autotune(x)                # once per distinct full-batch shape (the context keeps it)
-                    tuned.add(key)
-                labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes, labels_dtype=torch.uint8,
-                                                      small_zones=small_zones)   # models.py:269-276 on the device
-                slot = n_batches & 1
-                need = n * h * w
-                if ring[slot] is None or ring[slot][0].numel() < need or ring[slot][1].shape[0] < n:
-                    ring[slot] = (torch.empty(max(need, batch * h * w), dtype=torch.uint8).pin_memory(),
-                                  torch.empty((max(n, batch), 3), dtype=torch.int64).pin_memory())
-                ring[slot][0][:need].copy_(labels.reshape(-1), non_blocking=True)
-                ring[slot][1][:n].copy_(counts, non_blocking=True)
-                ring_ev[slot].record()
-                t2 = clock()
-                if pending is not None:
-                    consume(pending)                 # the previous batch's labels, while this one runs
-                prof["main.pack_and_h2d"] += t1 - t0; prof["main.launch"] += t2 - t1; prof["main.consume"] += clock() - t2
-                pending = (slot, [(k, mine[k]) for k in part], n, h, w)
-                n_batches += 1
-        frames.clear()
-    if pending is not None:
-        consume(pending)
-    for f in done:
-        f.result()
-    pool.shutdown()
-    sys.setswitchinterval(switch)
+    try:
+        windows = [list(range(a, min(a + window, len(mine)))) for a in range(0, len(mine), window)]
+        futs = {k: pool.submit(prepare, mine[k]) for k in (windows[0] if windows else [])}
+        t_loop = time.perf_counter()
+        for wi, win in enumerate(windows):
+            if wi + 1 < len(windows):                    # the pool starts on the next window before the GPU gets this one
+                for k in windows[wi + 1]:
+                    futs[k] = pool.submit(prepare, mine[k])
+            t0 = clock()
+            frames = {k: futs.pop(k).result() for k in win}
+            prof["main.wait_for_frames"] += clock() - t0
+            groups = defaultdict(list)
+            for k in win:
+                groups[frames[k].shape].append(k)
+            for shape, ks in sorted(groups.items()):
+                shape_count[shape] += len(ks)
+                for a in range(0, len(ks), batch):
+                    part = ks[a:a + batch]
+                    n, (h, w) = len(part), shape[:2]
+                    t0 = clock()
+                    st = stage[n_batches & 1]                 # pinned staging pair: frames are packed while the GPU runs the batch before
+                    if st["buf"] is None or st["buf"].numel() < n * h * w * 3:
+                        st["buf"] = torch.empty(max(n, batch) * h * w * 3, dtype=torch.uint8).pin_memory()
+                    st["ev"].synchronize()                    # the copy that last read this buffer has finished
+                    xb = st["buf"][: n * h * w * 3].view(n, h, w, 3)
+                    xnp = xb.numpy()
+                    for j, k in enumerate(part):
+                        xnp[j] = frames[k]
+                    x = xb.to(dev, non_blocking=True)         # uint8 NHWC; normalised on the device
+                    st["ev"].record()
+                    t1 = clock()
+                    key = (n, h, w)
+                    if key not in tuned and n == batch and shape_count[shape] >= 2 * batch:
+                        model.autotune(x)                # once per distinct full-batch shape (the context keeps it)
+                        tuned.add(key)
+                    labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes, labels_dtype=torch.uint8,
+                                                          small_zones=small_zones)   # models.py:269-276 on the device
+                    slot = n_batches & 1
+                    need = n * h * w
+                    if ring[slot] is None or ring[slot][0].numel() < need or ring[slot][1].shape[0] < n:
+                        ring[slot] = (torch.empty(max(need, batch * h * w), dtype=torch.uint8).pin_memory(),
+                                      torch.empty((max(n, batch), 3), dtype=torch.int64).pin_memory())
+                    ring[slot][0][:need].copy_(labels.reshape(-1), non_blocking=True)
+                    ring[slot][1][:n].copy_(counts, non_blocking=True)
+                    ring_ev[slot].record()
+                    t2 = clock()
+                    if pending is not None:
+                        consume(pending)                 # the previous batch's labels, while this one runs
+                    prof["main.pack_and_h2d"] += t1 - t0; prof["main.launch"] += t2 - t1; prof["main.consume"] += clock() - t2
+                    pending = (slot, [(k, mine[k]) for k in part], n, h, w)
+                    n_batches += 1
+            frames.clear()
+        if pending is not None:
+            consume(pending)
+        for f in done:
+            f.result()
+    finally:                                         # also on an exception from a worker: no stray threads, switch interval restored
+        pool.shutdown(wait=True, cancel_futures=True)
+        sys.setswitchinterval(switch)
     torch.cuda.synchronize()
     t_done = time.perf_counter()
 
