@@ -141,9 +141,8 @@ __global__ __launch_bounds__(THREADS, 2) void conv_igemm_kernel(const ConvArgs p
         if (++ld_kw == p.KW) { ld_kw = 0; ++ld_kh; }
       }
     } else {
-      const int tap = t * 8 + lc;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
-      const bool tap_ok = tap < p.KH * p.KW;
+      const int kh = t, kw = lc;                   // one kernel row per K-step, eight slots (kw < KW used)
+      const bool tap_ok = lc < p.KW;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int iy = a_iy0[i] + kh * p.dil, ix = a_ix0[i] + kw * p.dil;
@@ -297,7 +296,7 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s) {
   if (a.x_bytes == 0 || a.x_bytes >= 0x80000000u || a.w_bytes == 0 || a.w_bytes >= 0x80000000u)
     return hipErrorInvalidValue;     // 32-bit range-checked buffer offsets
   if (a.stem) {
-    if (a.Ci * eb != 16 || a.ksteps * 8 < a.KH * a.KW) return hipErrorInvalidValue;
+    if (a.Ci * eb != 16 || a.ksteps != a.KH || a.KW > 8) return hipErrorInvalidValue;
   } else {
     if ((a.Ci * eb) % 128 != 0 || a.ksteps != a.KH * a.KW * (a.Ci * eb / 128)) return hipErrorInvalidValue;
   }

@@ -199,10 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   const int cblocks = STEM ? 1 : pix_bytes / 128;                 // K-steps per tap
   int ld_kh = 0, ld_kw = 0, ld_cb = 0;
   int st_kh = 0, st_kw = 0;                                       // stem only: the lane's tap, see issue_one
-  if constexpr (STEM) {
-    st_kw = a_coff[0] >> 4;
-    while (st_kw >= p.KW) { st_kw -= p.KW; ++st_kh; }
-  }
+  if constexpr (STEM) st_kw = a_coff[0] >> 4;       // the lane's slot in every kernel row
 
   // Byte offsets of the activation rows for the CURRENT tap (channel block 0).  Inside a tap a K-step only
   // moves 128 bytes along the channels: that is the DMA's scalar offset (ld_cb * 128), so a K-step costs no
@@ -228,11 +225,12 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
       if constexpr (!STEM) {
         dma16_buf(a_off[i], xrsrc, sa + (unsigned)(ROWS_PER_PASS * 128 * i), (unsigned)ld_cb * 128u);
       } else {
-        // stem: one chunk = one tap's padded pixel; this lane's tap of the K-step being issued is
-        // (st_kh, st_kw), advanced by 8 taps per K-step without a division (all passes of a lane
-        // share the chunk: ROWS_PER_PASS is a multiple of 16)
+        // stem: one chunk = one tap's padded pixel, one K-step = one kernel row: this lane's tap of the
+        // K-step being issued is (st_kh = the step, st_kw = the lane's chunk; slots beyond KW stay zero), so the
+        // eight chunks of a row are consecutive input pixels (all passes of a lane share the chunk:
+        // ROWS_PER_PASS is a multiple of 16)
         const int iy = a_iy0[i] + st_kh * p.dil, ix = a_ix0[i] + st_kw * p.dil;
-        const bool ok = st_kh < p.KH && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const bool ok = st_kw < p.KW && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
         const unsigned off = (unsigned)(a_img[i] + iy * p.Wi + ix) * 16u;
         dma16_buf(ok ? off : kOutOfRange, xrsrc, sa + (unsigned)(ROWS_PER_PASS * 128 * i), 0u);
       }
@@ -250,10 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
     for (int d = 0; d < L; ++d)
       if (d * 4 / L == part) issue_one(d, t, sa);
     if constexpr (STEM) {
-      if (part == 3) {                             // next K-step: eight taps further
-        st_kw += 8;
-        while (st_kw >= p.KW) { st_kw -= p.KW; ++st_kh; }
-      }
+      if (part == 3) ++st_kh;                      // next K-step: next kernel row
     }
     if constexpr (!STEM) {
       if (part == 3) {
@@ -833,7 +828,7 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
       a.w_bytes >= kOutOfRange)
     return hipErrorInvalidValue;
   if (a.stem) {
-    if (a.Ci * eb != 16 || a.ksteps * 8 < a.KH * a.KW) return hipErrorInvalidValue;
+    if (a.Ci * eb != 16 || a.ksteps != a.KH || a.KW > 8) return hipErrorInvalidValue;
   } else {
     if ((a.Ci * eb) % 128 != 0 || a.ksteps != a.KH * a.KW * (a.Ci * eb / 128)) return hipErrorInvalidValue;
   }

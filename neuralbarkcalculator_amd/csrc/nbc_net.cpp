@@ -112,8 +112,10 @@ PackedLayout packed_layout(int precision) {
       off = align_up(off + (size_t)c.cout * 4, 256);
     } else {
       if (p.stem) {
+        // one 16-byte chunk per tap; a K-step is one kernel ROW: its kw taps + zero slots up to eight (k <= 8),
+        // so a K-step of an output pixel reads consecutive input pixels (one 128-byte segment)
         p.cin_pad = kChunkBytes / eb;
-        p.ksteps = (c.k * c.k + 7) / 8;
+        p.ksteps = c.k;
       } else {
         p.cin_pad = c.cin;
         p.ksteps = c.k * c.k * c.cin * eb / kKStepBytes;
@@ -248,7 +250,8 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
         for (int kw = 0; kw < c.k; ++kw)
           for (int ci = 0; ci < c.cin; ++ci) {
             const float v = w[(((size_t)o * c.cin + ci) * c.k + kh) * c.k + kw];
-            const size_t kidx = (size_t)(kh * c.k + kw) * p.cin_pad + ci;
+            const size_t kidx = p.stem ? (size_t)(kh * 8 + kw) * p.cin_pad + ci      // stem: eight slots per kernel row
+                                       : (size_t)(kh * c.k + kw) * p.cin_pad + ci;
             if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;
             else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
           }

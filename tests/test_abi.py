@@ -119,7 +119,10 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
         want = np.zeros((u.cout, row), np.float32)
         khkwci = w.transpose(0, 2, 3, 1)                       # [O][kh][kw][I]
         for tap in range(u.k * u.k):
-            want[:, tap * cin_pad: tap * cin_pad + u.cin] = khkwci[:, tap // u.k, tap % u.k, :]
+            # the stem keeps one kernel ROW per 128-byte K-step (eight 16-byte slots, kw of them used), so that a
+            # K-step of an output pixel reads consecutive input pixels; every other conv is [kh][kw][Cin]
+            slot = (tap // u.k) * 8 + tap % u.k if u.cin == 3 else tap
+            want[:, slot * cin_pad: slot * cin_pad + u.cin] = khkwci[:, tap // u.k, tap % u.k, :]
         if prec == 1:
             want = torch.from_numpy(want).to(torch.bfloat16).float().numpy()   # RNE like the packer
         np.testing.assert_array_equal(got, want, err_msg=u.name)
