@@ -185,10 +185,10 @@ int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_
                       int out_h, int out_w, void* hip_stream);
 
 /* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
- * register-staged reference kernel; tile = -1 (per-layer choice) or 0..11 = 128x64, 128x128,
+ * register-staged reference kernel; tile = -1 (per-layer choice) or 0..12 = 128x64, 128x128,
  * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave
- * 128x128 and 128x64 and the 16-wave 256x128 (pixels x channels), forced wherever the layer's Cout
- * allows it. */
+ * 128x128 and 128x64, the 16-wave 256x128 and (bf16) the 16-wave 256x256 (pixels x channels), forced wherever
+ * the layer's Cout and the precision allow it. */
 int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
 
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
       if (m < p.M) {
         // integer division by a run-time value costs ~30 VALU instructions each; the common
         // shapes avoid both (one image: no image index; power-of-two width: a shift)
-        const int img = p.N == 1 ? 0 : m / hw;
+        const int img = p.N == 1 ? 0 : (p.hw_shift >= 0 ? (m >> p.hw_shift) : m / hw);
         const int rem = m - img * hw;
         const int oy = p.wo_shift >= 0 ? (rem >> p.wo_shift) : rem / p.Wo;
         const int ox = rem - oy * p.Wo;
@@ -770,6 +770,9 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   9   128x128   4x2            32x64      2       70 KiB   2   (8 waves: short-K layers, where the
 //   10  128x64    4x2            32x32      2       48 KiB   3    serial prologue/epilogue code dominates
 //   11  256x128   4x4            64x32      2       96 KiB   1    and more waves run it in parallel)
+//   12  256x256   4x4            64x64      2       128 KiB  1   (bf16: short-K layers at batch >= 2; the matrix pipe is
+//                                                               busier than with 8 waves, the clock lower: same TFLOP/s on
+//                                                               long-K layers, 2-5 % faster epilogue-heavy 1x1 layers)
 template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   switch (tile) {
@@ -787,12 +790,15 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 9: return launch_cfg<PREC, 4, 2, 1, 2, PREC == 0 ? 3 : 2, STEM, VAR>(a, s);    // f32: three slots (96 KiB, fragment prefetch)
     case 10: return launch_cfg<PREC, 4, 2, 1, 1, PREC == 0 ? 3 : 2, STEM, VAR>(a, s);   // f32: 72 KiB, two blocks per CU
     case 11: return launch_cfg<PREC, 4, 4, 2, 1, 2, STEM, VAR>(a, s);
+    case 12:
+      if constexpr (PREC == 0) return hipErrorInvalidValue;
+      else return launch_cfg<PREC, 4, 4, 2, 2, 2, STEM, VAR>(a, s);   // bf16 only (f32: 128-register budget)
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256};
 
 }  // namespace
 
@@ -805,7 +811,7 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 // Whether tile id `tile` exists for this precision and divides the layer's output channels.
 bool conv_tile_ok(int precision, int tile, int Co) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
-  if (precision == 0 && tile == 3) return false;            // the f32 kernel keeps two accumulator sets
+  if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
   return Co % kTileCols[tile] == 0;
 }
 

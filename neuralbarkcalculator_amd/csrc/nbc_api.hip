@@ -263,8 +263,11 @@ int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream
   a.relu = u.relu ? 1 : 0;
   a.stem = pc.stem ? 1 : 0;
   a.wo_shift = -1;
-  for (int sft = 0; sft < 31; ++sft)
+  a.hw_shift = -1;
+  for (int sft = 0; sft < 31; ++sft) {
     if ((1 << sft) == o.Wo) a.wo_shift = sft;
+    if ((1 << sft) == o.Ho * o.Wo) a.hw_shift = sft;
+  }
   if (o.Ci != pc.cin_pad) return set_error(NBC_ERR_STATE, "plan/channel mismatch at " + o.name);
   const size_t xb = (size_t)N * o.Hi * o.Wi * o.Ci * elem_bytes(prec);
   const size_t wbts = (size_t)o.Co * pc.ksteps * kKStepBytes;

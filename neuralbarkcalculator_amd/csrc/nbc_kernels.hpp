@@ -25,6 +25,7 @@ struct ConvArgs {
   int relu;
   int stem;             // one 16-byte chunk per tap (Ci*elem == 16 bytes)
   int wo_shift;         // log2(Wo) when Wo is a power of two, else -1
+  int hw_shift;         // log2(Ho*Wo) when it is a power of two, else -1 (batches: image index without a division)
 #ifdef NBC_STAMPS
   unsigned long long* stamps;   // diagnostic build only (tools/conv_timeline.hip): 8 stamps per block
 #endif
@@ -35,7 +36,7 @@ struct ConvArgs {
 hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
 
 // v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co).
-constexpr int CONV_TILE_COUNT = 12;   // tile menu: see launch_tile() in conv_igemm_dma.hip
+constexpr int CONV_TILE_COUNT = 13;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 bool conv_tile_ok(int precision, int tile, int Co);   // the tile exists for the precision and divides Co

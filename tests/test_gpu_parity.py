@@ -251,7 +251,7 @@ def test_errors_are_python_exceptions(gpu_fp32):
         FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
 
 
-@pytest.mark.parametrize("impl,tile", [(0, -1)] + [(1, t) for t in range(12)])
+@pytest.mark.parametrize("impl,tile", [(0, -1)] + [(1, t) for t in range(13)])
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, impl, tile):
     """Each conv kernel instantiation (register-staged v1; LDS-DMA v2 at every tile shape) against
@@ -288,12 +288,12 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
     try:
         model.set_conv_impl(1, -1)
         base = model(x)
-        for tile in range(12):
+        for tile in range(13):
             model.set_conv_impl(1, tile)
             assert torch.equal(model(x), base), f"tile {tile} changes the logits"
         model.set_conv_impl(1, -1)
         tiles = model.autotune(x, reps=2)
-        assert len(tiles) == 54 and all(0 <= t < 12 for t in tiles)
+        assert len(tiles) == 54 and all(0 <= t < 13 for t in tiles)
         assert torch.equal(model(x), base)
     finally:
         model.set_conv_impl(1, -1)
@@ -427,14 +427,15 @@ def test_plan_cache_keeps_each_shapes_tiles(gpu_bf16):
 
 
 def test_fp32_has_no_256x256_tile(gpu_fp32):
-    """Tile 3 needs 2 x 128 accumulator registers in the two-level f32 kernel: forcing it falls back to the plan's tile."""
+    """Tiles 3 and 12 (256x256) need more accumulator registers than the two-level f32 kernel has: forcing them falls back to the plan's tile."""
     x = frames([73], 64, 72).to(DEV)
     base = gpu_fp32.lowres_logits(x)
     tiles = gpu_fp32.plan_tiles()
-    assert 3 not in tiles
+    assert 3 not in tiles and 12 not in tiles
     try:
-        gpu_fp32.set_conv_impl(1, 3)
-        assert torch.equal(gpu_fp32.lowres_logits(x), base)
+        for t in (3, 12):
+            gpu_fp32.set_conv_impl(1, t)
+            assert torch.equal(gpu_fp32.lowres_logits(x), base)
         with pytest.raises(RuntimeError):
             gpu_fp32.set_plan_tiles([3 if i > 40 else t for i, t in enumerate(tiles)])
     finally:

@@ -55,8 +55,8 @@ int main(int argc, char** argv) {
   a.x = dx; a.w = dw; a.scale = ds; a.shift = db; a.res = res ? dr : nullptr; a.y = dy;
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.N = 1; a.Hi = Hi; a.Wi = Wi; a.Ci = Ci; a.Ho = Hi; a.Wo = Wi; a.Co = Co;
   a.KH = a.KW = K; a.stride = 1; a.pad = dil * (K / 2); a.dil = dil; a.M = M; a.ksteps = ksteps; a.relu = 1; a.stem = 0;
-  a.wo_shift = -1;
-  for (int s = 0; s < 16; ++s) if ((1 << s) == Wi) a.wo_shift = s;
+  a.wo_shift = -1; a.hw_shift = -1;
+  for (int s = 0; s < 30; ++s) { if ((1 << s) == Wi) a.wo_shift = s; if ((1 << s) == Hi * Wi) a.hw_shift = s; }
   a.stamps = nullptr;
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
