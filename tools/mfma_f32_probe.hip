@@ -3,6 +3,9 @@
 // (the f32 conv kernel's wave tile), optionally with the things the conv kernel has around them:
 //   bit 0  one s_barrier per K-step            bit 1  16 ds_read_b128 per K-step feeding the MFMAs
 //   bit 2  64 v_add_f32 per K-step (two-level sum)   bit 3  6 LDS-DMAs (1 KiB each) per K-step
+//   bit 5  accumulators in AGPRs (inline-asm MFMA) instead of arch VGPRs
+//   bit 6  accumulators in AGPRs, compiler-scheduled (builtin MFMA; an inline-asm AGPR operand elsewhere in the
+//          kernel makes hipcc select the AGPR form)
 // Prints cycles per MFMA per SIMD (64 = the pipe's rate) for every combination asked for.
 //   tools/_bin/mfma_f32_probe
 #include <hip/hip_runtime.h>
@@ -21,6 +24,7 @@ __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ src, f
   for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = src[i];
   __syncthreads();
   f32x16 acc[4], accI[4];
+  if (MASK & 64) { float z = 0.f; asm volatile("; an AGPR operand: hipcc then selects the AGPR form of every MFMA %0" ::"a"(z)); }
   for (int t = 0; t < 4; ++t)
     for (int e = 0; e < 16; ++e) { acc[t][e] = 0.f; accI[t][e] = 0.f; }
   float4 a[2][2], b[2][2];
@@ -44,7 +48,8 @@ __global__ __launch_bounds__(512, 2) void probe(const float* __restrict__ src, f
         const float we[4] = {wv.x, wv.y, wv.z, wv.w}, pe[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (MASK & 4) accI[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(we[e], pe[e], (ks == 0 && e == 0) ? zero : accI[n], 0, 0, 0);
+          if (MASK & 32) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[n]) : "v"(we[e]), "v"(pe[e]));      // accumulators in AGPRs
+          else if (MASK & 4) accI[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(we[e], pe[e], (ks == 0 && e == 0) ? zero : accI[n], 0, 0, 0);
           else acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(we[e], pe[e], acc[n], 0, 0, 0);
           if ((MASK & 2) && (MASK & 16) && e == 0) {      // spread: one fragment read behind the first MFMA of each tile
             if (n == 0) a[(ks + 1) & 1][0] = p[0];
@@ -100,8 +105,8 @@ int run(int waves, const float* src, float* out, unsigned long long* cyc, int st
   for (auto v : h) mean += (double)v;
   mean /= blocks;
   const double per = mean / ((double)steps * 64.0 * (waves / 4));     // cycles per MFMA per SIMD
-  std::printf("  %d waves/SIMD  barrier %d  ds_read %d  adds %d  dma %d  spread %d : %.2f cycles per MFMA per SIMD  (pipe busy %.3f)\n", waves / 4, MASK & 1,
-              (MASK >> 1) & 1, (MASK >> 2) & 1, (MASK >> 3) & 1, (MASK >> 4) & 1, per, 64.0 / per);
+  std::printf("  %d waves/SIMD  barrier %d  ds_read %d  adds %d  dma %d  spread %d  agpr %d : %.2f cycles per MFMA per SIMD  (pipe busy %.3f)\n", waves / 4, MASK & 1,
+              (MASK >> 1) & 1, (MASK >> 2) & 1, (MASK >> 3) & 1, (MASK >> 4) & 1, (MASK >> 5) & 3, per, 64.0 / per);
   return 0;
 }
 
@@ -125,6 +130,18 @@ int main() {
     if (run<11 + 16>(waves, src, out, cyc, steps)) return 1;
     if (run<15>(waves, src, out, cyc, steps)) return 1;
     if (run<15 + 16>(waves, src, out, cyc, steps)) return 1;
+    if (run<9>(waves, src, out, cyc, steps)) return 1;
+    if (run<1 + 32>(waves, src, out, cyc, steps)) return 1;
+    if (run<3 + 32>(waves, src, out, cyc, steps)) return 1;
+    if (run<3 + 16 + 32>(waves, src, out, cyc, steps)) return 1;
+    if (run<9 + 32>(waves, src, out, cyc, steps)) return 1;
+    if (run<11 + 32>(waves, src, out, cyc, steps)) return 1;
+    if (run<1 + 64>(waves, src, out, cyc, steps)) return 1;
+    if (run<3 + 64>(waves, src, out, cyc, steps)) return 1;
+    if (run<9 + 64>(waves, src, out, cyc, steps)) return 1;
+    if (run<11 + 64>(waves, src, out, cyc, steps)) return 1;
+    if (run<7 + 64>(waves, src, out, cyc, steps)) return 1;
+    if (run<15 + 64>(waves, src, out, cyc, steps)) return 1;
   }
   return 0;
 }
