@@ -54,7 +54,7 @@ def parse(argv=None):
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32",
                     help="arithmetic of the HEADLINE run (fp32 = the reference's; bf16 only for A/B experiments)")
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent forwards kept in flight on separate HIP streams (each its own workspace)")
     ap.add_argument("--weights", choices=["random_init", "trained_like"], default="trained_like")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
