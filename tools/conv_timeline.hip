@@ -1,13 +1,16 @@
 // Diagnostic: where does a block of the LDS-DMA conv kernel spend its time?
 // Builds conv_igemm_dma.hip with -DNBC_STAMPS (thread 0 of every block stamps the 100 MHz wall clock
 // at phase boundaries) and runs ONE layer shape on random bf16 data.  Not part of the library.
-//   tools/_bin/conv_timeline Hi Wi Ci Co K dil res tile [mfma32]
+//   tools/_bin/conv_timeline Hi Wi Ci Co K dil res tile [streams [precision]]
+// NBC_WARM=n: n untimed launches first (short layers need ~2000 for the clock to settle at what a forward sees);
+// NBC_DUMP=1: one line per block (XCD, SE, CU, start, phases).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "nbc_kernels.hpp"
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
   a.stamps = nullptr;
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 20; ++i) CK(nbc::launch_conv_dma(a, prec, tile, st));
+  for (int i = 0; i < (getenv("NBC_WARM") ? atoi(getenv("NBC_WARM")) : 20); ++i) CK(nbc::launch_conv_dma(a, prec, tile, st));
   CK(hipEventRecord(e0, st));
   const int reps = 50;
   for (int i = 0; i < reps; ++i) CK(nbc::launch_conv_dma(a, prec, tile, st));
@@ -157,5 +160,13 @@ int main(int argc, char** argv) {
     maxc = std::max(maxc, conc);
   }
   std::printf("  CUs used %zu, blocks per CU max %zu, co-resident per CU max %zu\n", per_cu.size(), maxb, maxc);
+  if (getenv("NBC_DUMP")) {      // one line per block: where it ran and how long
+    for (int b = 0; b < nblk; ++b) {
+      const unsigned long long id = h[b * 64 + 7];
+      const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 0xf;
+      std::printf("blk %4d xcc %u se %u sh %u cu %2u simd0 %u start %7.2f first %6.2f kloop %7.2f total %7.2f\n", b, xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf,
+                  (hw >> 4) & 3, (h[b * 64] - t0) * 0.01, (h[b * 64 + 2] - h[b * 64]) * 0.01, (h[b * 64 + 3] - h[b * 64 + 2]) * 0.01, (h[b * 64 + 6] - h[b * 64]) * 0.01);
+    }
+  }
   return 0;
 }
