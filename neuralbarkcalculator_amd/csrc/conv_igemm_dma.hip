@@ -805,9 +805,6 @@ constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64,
 int conv_tile_rows(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTileRows[tile] : 0; }
 int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTileCols[tile] : 0; }
 
-// Default tile (before nbc_autotune measures): the largest tile that still yields at least one
-// tile per CU (256); when no shape does, the one with the most tiles.  Bigger tiles move fewer
-// L2->LDS bytes per FLOP.
 // Whether tile id `tile` exists for this precision and divides the layer's output channels.
 bool conv_tile_ok(int precision, int tile, int Co) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
@@ -815,15 +812,54 @@ bool conv_tile_ok(int precision, int tile, int Co) {
   return Co % kTileCols[tile] == 0;
 }
 
-int choose_conv_tile(int M, int Co, int precision) {
-  const int order[4] = {3, 2, 1, 0};
-  int best = -1, best_tiles = -1;
-  for (int k = 0; k < 4; ++k) {
-    const int t = order[k];
+// Default tile of a layer (what runs unless nbc_autotune has measured): the cheapest under a small cost model.
+// A launch takes as long as the CU with the most blocks: ceil(blocks / 256) blocks one after the other, each
+//   tile FLOPs / (per-CU matrix rate x eff[t])  +  ovh[t]  +  tile bytes x cb[t] / (50 GB/s)
+// (K = Cin*kh*kw products per output; tile bytes = the (rows + cols) x K operand panels + twice the output tile).
+// What matters most is the first factor: a 640x1024 image has 10 240 pixels at stride 8, so the head conv on
+// 128x128 tiles is 320 blocks = two rounds of which the second is a quarter full, on 64x128 tiles 640 blocks =
+// three per CU, a third faster.  Constants fitted to per-layer timings of every tile on 28 (precision, batch,
+// height) cases (scripts/tile_model_probe.py, scripts/fit_tile_model.py, profiles/r02_tile_model_fit.log):
+// the choice is within 0.1-0.5 % (f32) / 0.4-4.4 % (bf16) of the per-layer best, which is where nbc_autotune lands
+// too; the rule it replaces (largest tile that still gives 256 blocks) was 2-38 % off at heights other than 1024.
+namespace {
+struct TileModel {
+  double cu_flops_per_us;              // per-CU matrix rate the efficiencies refer to
+  double eff[CONV_TILE_COUNT], ovh_us[CONV_TILE_COUNT], cb[CONV_TILE_COUNT];
+};
+constexpr TileModel kTileModel[2] = {
+    // f32: 157.3 TF / 256 CUs
+    {157.3e6 / 256.0,
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85},
+     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
+    // bf16: against the 1 400 TF/s the chip sustains on this kernel (power-limited), / 256 CUs
+    {1400.0e6 / 256.0,
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85},
+     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61},
+     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0}}};
+}  // namespace
+
+int choose_conv_tile(int M, int Co, int K, int precision) {
+  if (precision != 0 && precision != 1) return -1;
+  const TileModel& tm = kTileModel[precision];
+  const double eb = precision == 0 ? 4.0 : 2.0;
+  int best = -1;
+  double best_cost = 0.0;
+  for (int t = 0; t < CONV_TILE_COUNT; ++t) {
     if (!conv_tile_ok(precision, t, Co)) continue;
-    const int tiles = ((M + conv_tile_rows(t) - 1) / conv_tile_rows(t)) * (Co / conv_tile_cols(t));
-    if (tiles >= 256) return t;
-    if (tiles > best_tiles) { best = t; best_tiles = tiles; }
+    const double rows = kTileRows[t], cols = kTileCols[t];
+    const long long blocks = (long long)((M + kTileRows[t] - 1) / kTileRows[t]) * (Co / kTileCols[t]);
+    const double rounds = (double)((blocks + 255) / 256);
+    const double flops = rows * cols * 2.0 * K;
+    const double bytes = (rows + cols) * K * eb + rows * cols * eb * 2.0;
+    const double cost = rounds * (flops / (tm.cu_flops_per_us * tm.eff[t]) + tm.ovh_us[t] + bytes * tm.cb[t] / 50.0e3);
+    // ties (to 1e-9 relative) go to the larger tile: fewer L2 -> LDS bytes per FLOP
+    if (best < 0 || cost < best_cost * (1.0 - 1e-9) ||
+        (cost <= best_cost * (1.0 + 1e-9) && rows * cols > (double)kTileRows[best] * kTileCols[best])) {
+      best = t;
+      best_cost = cost;
+    }
   }
   return best;
 }
@@ -838,7 +874,7 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   } else {
     if ((a.Ci * eb) % 128 != 0 || a.ksteps != a.KH * a.KW * (a.Ci * eb / 128)) return hipErrorInvalidValue;
   }
-  if (tile < 0) tile = choose_conv_tile(a.M, a.Co, precision);
+  if (tile < 0) tile = choose_conv_tile(a.M, a.Co, a.ksteps * (128 / eb), precision);
   if (!conv_tile_ok(precision, tile, a.Co)) return hipErrorInvalidValue;
   // NBC_CONV_ABLATE=1 (no MFMA) / 2 (no refill DMA): timing-only builds of the bf16 256x256 and
   // 128x256 tiles, results are garbage.  Never set outside an experiment.

@@ -141,7 +141,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
     o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
-    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, c->precision);
+    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
     o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +

@@ -35,12 +35,12 @@ struct ConvArgs {
 // v1: register-staged, 128 x {64,128} tiles (conv_igemm.hip); kept as the A/B reference kernel.
 hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
 
-// v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co).
+// v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
 constexpr int CONV_TILE_COUNT = 13;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 bool conv_tile_ok(int precision, int tile, int Co);   // the tile exists for the precision and divides Co
-int choose_conv_tile(int M, int Co, int precision);
+int choose_conv_tile(int M, int Co, int K, int precision);   // K = Cin*kh*kw; the default tile of a layer (cost model)
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
 
 // float32 NCHW [N,3,H,W] -> NHWC elements padded to 16 bytes per pixel.

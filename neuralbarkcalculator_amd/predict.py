@@ -332,7 +332,7 @@ def plan_items(root: str) -> List[dict]:
 
 def predict_folder(root: str, model_path: str = "./best_model.pt", precision: str = "fp32",
                    exclude_nodes: bool = False, small_zones: bool = True, device_index: int = None,
-                   batch: int = None, window: int = 64, target_size: int = 1024) -> dict:
+                   batch: int = None, window: int = 64, target_size: int = 1024, autotune: bool = False) -> dict:
     """predict.py:51-58 + models.py:230-364 with the model call on the MI355X path.
 
     One pass per image instead of the reference's two (preprocess everything, then predict everything):
@@ -340,7 +340,10 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     reference does), hands the uint8 frames to the GPU in windows of ``window`` images while the pool
     already works on the next window, runs equal-sized frames of a window as batches of up to ``batch``,
     and writes each label PNG from the pool as soon as its labels are on the host (pinned double
-    buffer, asynchronous copy).  Returns timing / count statistics of this rank."""
+    buffer, asynchronous copy).  Every shape runs on the library's default per-layer tiles (a cost model that
+    lands within 0.1-0.5 % of the measured best in f32); ``autotune=True`` measures them once per distinct
+    full-batch shape instead, which costs 0.5-0.9 s per shape and pays only for many thousands of images of one
+    shape.  Returns timing / count statistics of this rank."""
     import time
     import torch
     from collections import defaultdict
@@ -480,7 +483,7 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
                     st["ev"].record()
                     t1 = clock()
                     key = (n, h, w)
-                    if key not in tuned and n == batch and shape_count[shape] >= 2 * batch:
+                    if autotune and key not in tuned and n == batch and shape_count[shape] >= 2 * batch:
                         model.autotune(x)                # once per distinct full-batch shape (the context keeps it)
                         tuned.add(key)
                     labels, counts = model.predict_labels(x, exclude_nodes=exclude_nodes, labels_dtype=torch.uint8,
@@ -560,6 +563,8 @@ def main(argv=None):
     ap.add_argument("--no_small_zones", action="store_true")
     ap.add_argument("--gpus", type=int, default=1, help="shard the folder over N GPUs of this node (one process each, RCCL)")
     ap.add_argument("--batch", type=int, default=None, help="frames of equal size per forward (default 2 in fp32, 8 in bf16)")
+    ap.add_argument("--autotune", action="store_true",
+                    help="measure the conv tile shapes once per distinct full-batch image shape (0.5-0.9 s each) instead of the default choice")
     raw = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(raw)
     if args.only_preprocess:
@@ -574,7 +579,7 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and ":" in args.device:
         idx = int(args.device.split(":")[1])
     stats = predict_folder(args.root_path, args.model_path, args.precision, args.exclude_nodes,
-                           not args.no_small_zones, idx, batch=args.batch)
+                           not args.no_small_zones, idx, batch=args.batch, autotune=args.autotune)
     if stats["rank"] == 0:
         print("predicted %(images_total)d images (%(images_this_rank)d on rank 0, %(batches)d batches): %(total_s).2f s, "
               "%(images_per_s_loop).1f images/s in the loop on this rank" % stats)

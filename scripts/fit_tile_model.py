@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Fits the default-tile cost model of csrc/conv_igemm_dma.hip (choose_conv_tile) to the output of
+scripts/tile_model_probe.py and reports, per case, how far the model's choice, the rule it replaced and
+nbc_autotune's pick are from the per-layer best.   python scripts/fit_tile_model.py a.json b.json [--fit]
+Without --fit it evaluates the constants below (the ones compiled into the library).
+
+  cost(t) = ceil(blocks(t) / 256) * ( tile FLOPs / (per-CU rate * eff[t]) + ovh[t] + tile bytes * cb[t] / 50 GB/s )
+
+--fit: random coordinate search on the mean relative regret over the cases, pulled towards eff 0.85, ovh 4 us,
+cb 1 (f32: cb fixed at 0), then cross-validated between the two files."""
+import json
+import math
+import random
+import sys
+
+ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256]
+COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256]
+PEAK = {"fp32": 157.3e12 / 256 * 1e-3, "bf16": 1400e12 / 256 * 1e-3}          # FLOPs per ms per CU
+BYTE_MS = 1.0 / (50e9 * 1e-3)                                                # ms per byte at 50 GB/s
+MODEL = {
+    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85],
+                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * 13),
+    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85],
+                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61],
+                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0]),
+}
+
+
+def tile_ok(prec, t, co):
+    return not (prec == "fp32" and t in (3, 12)) and co % COLS[t] == 0
+
+
+def out_hw(name, h, w=1024):
+    s2 = lambda v: (v - 1) // 2 + 1
+    h1, w1 = s2(h), s2(w)
+    if name == "backbone.conv1":
+        return h1, w1
+    h2, w2 = s2(h1), s2(w1)
+    if name.startswith("backbone.layer1") or name == "backbone.layer2.0.conv1":
+        return h2, w2
+    return s2(h2), s2(w2)
+
+
+def load(path):
+    res = {}
+    for key, c in json.load(open(path)).items():
+        prec, b, h = key.split("_")
+        b, h = int(b[1:]), int(h[1:])
+        rows = []
+        for i, name in enumerate(c["names"]):
+            co = c["cout"][i]
+            ho, wo = out_hw(name, h)
+            M = b * ho * wo
+            rows.append(dict(co=co, M=M, K=c["flops"][i] / (2.0 * M * co), default_ms=c["default_ms"][i], tuned=c["tuned_tiles"][i],
+                             ts={t: c["per_tile"][str(t)][i] for t in range(13) if tile_ok(prec, t, co)}))
+        res[key] = rows
+    return res
+
+
+def pick(r, prec, p):
+    eb = 4 if prec == "fp32" else 2
+    best, best_cost = None, 0.0
+    for t in sorted(r["ts"]):
+        blocks = math.ceil(r["M"] / ROWS[t]) * (r["co"] // COLS[t])
+        flops = ROWS[t] * COLS[t] * 2.0 * r["K"]
+        nbytes = (ROWS[t] + COLS[t]) * r["K"] * eb + ROWS[t] * COLS[t] * eb * 2
+        cost = math.ceil(blocks / 256) * (flops / (PEAK[prec] * p["eff"][t]) + p["ovh"][t] * 1e-3 + nbytes * p["cb"][t] * BYTE_MS)
+        if best is None or cost < best_cost * (1 - 1e-9) or (cost <= best_cost * (1 + 1e-9) and ROWS[t] * COLS[t] > ROWS[best] * COLS[best]):
+            best, best_cost = t, cost
+    return best
+
+
+def regret(data, prec, p, verbose=False):
+    s = n = 0
+    for key, rows in data.items():
+        if not key.startswith(prec):
+            continue
+        best = sum(min(r["ts"].values()) for r in rows)
+        model = sum(r["ts"][pick(r, prec, p)] for r in rows)
+        old = sum(r["default_ms"] for r in rows)
+        tuned = sum(r["ts"].get(r["tuned"], r["default_ms"]) for r in rows)
+        if verbose:
+            print("  %-16s per-layer best %7.3f ms | model %7.3f (+%.1f %%) | plan's tiles at probe time %7.3f (+%.1f %%) | nbc_autotune %7.3f (+%.1f %%)"
+                  % (key, best, model, (model / best - 1) * 100, old, (old / best - 1) * 100, tuned, (tuned / best - 1) * 100))
+        s += model / best - 1
+        n += 1
+    return s / max(n, 1)
+
+
+def fit(data, prec, iters=8000, seed=1, lam=0.002):
+    random.seed(seed)
+    p = dict(eff=[0.85] * 13, ovh=[4.0] * 13, cb=[0.0 if prec == "fp32" else 1.0] * 13)
+    prior = {k: list(v) for k, v in p.items()}
+
+    def score(q):
+        pen = sum((a - b) ** 2 for a, b in zip(q["eff"], prior["eff"])) + 0.01 * sum((a - b) ** 2 for a, b in zip(q["ovh"], prior["ovh"])) \
+            + 0.1 * sum((a - b) ** 2 for a, b in zip(q["cb"], prior["cb"]))
+        return regret(data, prec, q) + lam * pen
+    best = score(p)
+    for _ in range(iters):
+        q = {k: list(v) for k, v in p.items()}
+        t, u = random.randrange(13), random.random()
+        if u < 0.4:
+            q["eff"][t] = min(1.0, max(0.45, q["eff"][t] + random.gauss(0, 0.05)))
+        elif u < 0.7 or prec == "fp32":
+            q["ovh"][t] = min(12.0, max(0.0, q["ovh"][t] + random.gauss(0, 1.0)))
+        else:
+            q["cb"][t] = min(4.0, max(0.0, q["cb"][t] + random.gauss(0, 0.2)))
+        r = score(q)
+        if r <= best:
+            best, p = r, q
+    return p
+
+
+def main():
+    files = [a for a in sys.argv[1:] if not a.startswith("--")]
+    sets = [load(f) for f in files]
+    everything = {}
+    for s in sets:
+        everything.update(s)
+    for prec in ("fp32", "bf16"):
+        if "--fit" in sys.argv:
+            if len(sets) == 2:
+                for a, b, tag in ((sets[0], sets[1], "first -> second"), (sets[1], sets[0], "second -> first")):
+                    p = fit(a, prec, iters=4000)
+                    print("%s cross-validation %s: mean regret %.2f %% on the fitted file, %.2f %% on the other"
+                          % (prec, tag, regret(a, prec, p) * 100, regret(b, prec, p) * 100))
+            p = fit(everything, prec)
+            print(prec, "fitted on all cases:", json.dumps({k: [round(v, 3) for v in vs] for k, vs in p.items()}))
+        else:
+            p = MODEL[prec]
+        print("%s: mean regret of the model's choice %.2f %%" % (prec, regret(everything, prec, p) * 100))
+        regret(everything, prec, p, verbose=True)
+
+
+if __name__ == "__main__":
+    main()
