@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end folder prediction on one GPU (BASELINE.json configs[3] per rank; next rows N1-N3): a synthetic
 folder of 1024x1024 .bmp samples -> decode, preprocess, processed/ PNG, forward + remove_small_zones, label
-PNG, CSV.  usage: python scripts/time_folder.py [n_images=1000] [precisions=bf16,fp32]
+PNG, CSV.  usage: python scripts/time_folder.py [n_images=1000] [precisions=bf16,fp32] [ragged]
+"ragged": every scan has black bands at the top and bottom, so that trim_black leaves heights of 520-730 rows (what
+the reference's real folders look like: res/*.png): hundreds of distinct image shapes in one folder.
 NBC_HOST_WORKERS sets the host thread pool (default 16, the GPU box's CPU share per GPU)."""
 import json
 import os
@@ -19,6 +21,7 @@ from neuralbarkcalculator_amd import predict as drv, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 precisions = (sys.argv[2] if len(sys.argv) > 2 else "bf16,fp32").split(",")
+ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
 distinct = min(n, 40)
 root = tempfile.mkdtemp(prefix="nbc_folder_")
 try:
@@ -28,11 +31,22 @@ try:
         os.makedirs(os.path.join(root, "samples", wood))
     with ThreadPoolExecutor(16) as pool:
         frames = list(pool.map(lambda i: synth.make_frame(i, 1024, 1024), range(distinct)))
-        list(pool.map(lambda i: Image.fromarray(frames[i % distinct], mode="RGB").save(
+
+        def scan(i):
+            f = frames[i % distinct]
+            if not ragged:
+                return f
+            g = f.copy()
+            band = 294 + (i * 37) % 211                  # black rows in all: 294..504 -> 520..730 rows stay
+            top = (i * 13) % (band + 1)
+            g[:top] = 0
+            g[1024 - (band - top):] = 0
+            return g
+        list(pool.map(lambda i: Image.fromarray(scan(i), mode="RGB").save(
             os.path.join(root, "samples", woods[i % 3], "f%04d.bmp" % i)), range(n)))
     ckpt = os.path.join(root, "best_model.pt")
     torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict("trained_like", seed=7).items()}, ckpt)
-    print(f"folder of {n} synthetic 1024x1024 .bmp samples ({distinct} distinct frames) made in {time.perf_counter() - t0:.1f} s; "
+    print(f"folder of {n} synthetic 1024x1024 .bmp samples ({distinct} distinct frames{', black bands: 520-730 rows after trim_black' if ragged else ''}) made in {time.perf_counter() - t0:.1f} s; "
           f"host workers {drv._host_workers()}, cores available {len(os.sched_getaffinity(0))}", flush=True)
     for prec in precisions:
         for rep in range(2):                  # second run: page cache and allocator warm
