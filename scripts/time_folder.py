@@ -58,7 +58,7 @@ try:
             rows = open(os.path.join(root, "results", "final_stats.csv")).read().count("\n") - 1
             print(f"{prec} run {rep}: {n} images end to end in {dt:.2f} s = {n / dt:.1f} images/s "
                   f"(checkpoint load + weight packing + upload {st['setup_s']:.2f} s included); steady loop {st['images_per_s_loop']:.1f} "
-                  f"images/s; CSV rows {rows}; {json.dumps({k: st[k] for k in ('batch', 'batches', 'distinct_shapes', 'autotuned_shapes', 'host_workers')})}",
+                  f"images/s; CSV rows {rows}; {json.dumps({k: st[k] for k in ('batch', 'batches', 'streams', 'distinct_shapes', 'autotuned_shapes', 'host_workers')})}",
                   flush=True)
 finally:
     shutil.rmtree(root, ignore_errors=True)
