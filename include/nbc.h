@@ -194,7 +194,10 @@ int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real
  * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the
  * current (N,H,W) plan (`reps` launches each, HIP events) and keeps the fastest.  Results do not
- * depend on the tile (same K order, one accumulator per output), only speed does.  The choice is
+ * depend on the tile (same K order, one accumulator per output), only speed does.  Without this call a
+ * plan runs on per-layer defaults from a cost model (rounds of blocks per CU x per-block time, fitted to
+ * measurements), within 0.1-0.6 % (f32) / 0.5-4.4 % (bf16) of the measured best at any image height; the
+ * measurement costs 0.5-0.9 s per shape.  The choice is
  * part of the plan; the context keeps the plans (and choices) of the last 64 shapes it has seen, so a
  * folder of height-trimmed images tunes each distinct (N,H,W) once.
  * nbc_get_plan_tiles copies the tile id of each conv launch of the plan; returns their number. */
