@@ -528,7 +528,9 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         print("rank %d stage seconds (pool stages summed over %d threads): %s; loop wall %.2f s" %
               (rank, workers, ", ".join("%s %.2f" % kv for kv in sorted(prof.items())), t_done - t_loop), flush=True)
     cap = max(len(s) for s in shards) if shards else 0
-    allrows = gather_rows(rows, n_total, world, dist, dev, cap=cap)
+    # RCCL gathers device tensors; a gloo group (one-GPU rehearsals of the multi-rank path) gathers on the host
+    gather_dev = dev if dist is not None and dist.get_backend() == "nccl" else None
+    allrows = gather_rows(rows, n_total, world, dist, gather_dev, cap=cap)
     if rank == 0:
         write_stats_csv(os.path.join(root, "results", "final_stats.csv"),
                         [stats_row(items[int(r[0])]["name"], items[int(r[0])]["wood"], int(r[1]), int(r[2]), int(r[3]), int(r[4]))

@@ -124,3 +124,42 @@ def test_two_rank_folder_over_rccl(tmp_path, sd_np, built_lib):
     assert outs[0][1] == outs[1][1] and len(outs[0][0]) == 9
     for a, b in zip(outs[0][0], outs[1][0]):
         assert np.array_equal(a, b)
+
+
+def test_two_rank_folder_rehearsal_on_one_gpu(tmp_path, sd_np, built_lib):
+    """The multi-rank folder path on a one-GPU box: two ranks (torch.distributed.run, gloo) that both use cuda:0.
+    Rank 0 alone reads the checkpoint, the packed weights travel by broadcast, each rank predicts its contiguous
+    pixel-balanced shard, the rows are gathered and rank 0 writes the CSV: same files as one rank."""
+    import subprocess
+    import sys
+    layout = [("epinette_gelee" if i < 4 else "sapin", "s%02d.bmp" % i, 60 + i, 96 + 8 * (i % 4), 160) for i in range(10)]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for world in (1, 2):
+        root = str(tmp_path / ("w%d" % world))
+        ckpt, _ = _make_folder(root, sd_np, layout)
+        code = ("import sys, torch.distributed as dist\n"
+                "sys.path.insert(0, %r)\n"
+                "from neuralbarkcalculator_amd import predict\n"
+                "dist.init_process_group('gloo')\n"
+                "st = predict.predict_folder(%r, %r, device_index=0)\n"
+                "assert st['world'] == %d and 0 < st['images_this_rank'] < 10 or st['world'] == 1\n"
+                "dist.destroy_process_group()\n" % (repo, root, ckpt, world))
+        script = tmp_path / ("run%d.py" % world)
+        script.write_text(code)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                            "--master-addr", "127.0.0.1", "--master-port", str(29611 + world), str(script)],
+                           cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        labs = {}
+        for wood in ("epinette_gelee", "sapin"):
+            d = os.path.join(root, "results", "outputs", wood)
+            for n in sorted(os.listdir(d)):
+                labs[(wood, n)] = np.asarray(Image.open(os.path.join(d, n)))
+        outs.append((labs, open(os.path.join(root, "results", "final_stats.csv")).read()))
+    assert outs[0][1] == outs[1][1] and len(outs[0][0]) == 10 and outs[0][0].keys() == outs[1][0].keys()
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
