@@ -385,7 +385,9 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     if dist is not None:
         model.broadcast_weights(src=0)
     models = [model] + [model.clone_shared() for _ in range(n_streams - 1)]
-    gpu_streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    # side streams only: the default stream stays with the pool's device resizes (pre_model)
+    gpu_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    torch.cuda.synchronize(dev)                      # weights uploaded / received before any side stream reads them
     t_ready = time.perf_counter()
 
     items = plan_items(root)
