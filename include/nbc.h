@@ -205,6 +205,10 @@ int nbc_autotune(nbc_ctx* ctx, const void* x_dev, int x_dtype, int N, int H, int
                  void* hip_stream);   /* objective 0: time of the launch alone; 1: time x fraction of the 256
                                          CUs it occupies (forwards overlapped on several streams) */
 int nbc_get_plan_tiles(nbc_ctx* ctx, int32_t* tiles, int capacity);
+/* The default tile id the cost model gives a convolution with M = N*Ho*Wo output pixels, Cout output channels and
+ * K = Cin*kh*kw products per output (host arithmetic only: no device needed); -1 for an unknown precision or a Cout
+ * no tile divides. */
+int nbc_default_conv_tile(int M, int Cout, int K, int precision);
 /* Install a tile choice (one id per conv launch of the current plan, as nbc_get_plan_tiles returns them),
  * e.g. one measured in an earlier process: NBC_ERR_INVALID when the count or a tile does not fit. */
 int nbc_set_plan_tiles(nbc_ctx* ctx, const int32_t* tiles, int n);

@@ -622,6 +622,11 @@ int nbc_get_plan_tiles(nbc_ctx* c, int32_t* tiles, int capacity) {
   return n;
 }
 
+int nbc_default_conv_tile(int M, int Cout, int K, int precision) {
+  if (M < 1 || Cout < 1 || K < 1) return -1;
+  return choose_conv_tile(M, Cout, K, precision);
+}
+
 int nbc_set_plan_tiles(nbc_ctx* c, const int32_t* tiles, int n) {
   if (!c || !tiles) return set_error(NBC_ERR_INVALID, "nbc_set_plan_tiles: null argument");
   int convs = 0;

@@ -158,3 +158,31 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libnbc_hip.so"))
     with pytest.raises(RuntimeError, match="only implementation"):
         FCNResNet50("fp32")
+
+
+def test_default_conv_tile_cost_model(built_lib):
+    """Host logic of the per-layer default tile (csrc/conv_igemm_dma.hip, choose_conv_tile): a valid tile for the
+    precision and channel count, and the choices that matter most, where whole rounds of blocks on 256 CUs decide."""
+    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256]
+    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256]
+    f = built_lib.nbc_default_conv_tile
+    for prec in (0, 1):
+        for co in (64, 128, 256, 512, 1024, 2048):
+            for m in (64, 1000, 8448, 9984, 16384, 65536, 131072, 524288):
+                for k in (64, 576, 2048, 18432):
+                    t = f(m, co, k, prec)
+                    assert 0 <= t < 13 and co % cols[t] == 0
+                    assert not (prec == 0 and t in (3, 12))            # f32 has no 256x256 tile
+    assert f(16384, 96, 64, 0) == -1 and f(16384, 512, 64, 7) == -1 and f(0, 512, 64, 0) == -1
+    blocks = lambda t, m, co: -(-m // rows[t]) * (co // cols[t])
+    # the head conv (3x3, 2048 -> 512) in f32 at 1024x1024: 16 384 pixels, one 256x128 / 128x256 tile per CU
+    t = f(16384, 512, 18432, 0)
+    assert rows[t] * cols[t] == 32768 and blocks(t, 16384, 512) == 256
+    # the same layer for a 640-row scan (10 240 pixels): not 320 blocks of 128x128 (two rounds, the second a quarter
+    # full) but 640 small ones, three per CU
+    t = f(10240, 512, 18432, 0)
+    assert rows[t] * cols[t] == 8192 and blocks(t, 10240, 512) == 640
+    # bf16 at batch 8: the big layers run on 256x256 tiles
+    assert rows[f(131072, 512, 18432, 1)] * cols[f(131072, 512, 18432, 1)] == 65536
+    # the stem (Cout 64) only has 64-column tiles to choose from
+    assert cols[f(262144, 64, 147, 0)] == 64 and cols[f(262144, 64, 147, 1)] == 64
