@@ -5,13 +5,18 @@ usage: per_forward_table.py <prof_dir> <out.json> --precision fp32|bf16 --batch 
   <prof_dir>/trace   rocprofv3 --kernel-trace --stats -- python3 bench.py ... --dump-ops <prof_dir>/ops.json
   <prof_dir>/fetch   rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py ... --no-op-events   (optional)
   <prof_dir>/write   rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py ... --no-op-events   (optional)
+  <prof_dir>/mfma    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- ...           (optional)
 
 A forward is the run of nbc kernels from an `ingest` kernel to the next `upsample_argmax` with exactly the
 plan's number of launches in between; the autotune launches (conv kernels with no ingest in front) are
 therefore never counted.  Forward 0 is autotune's own, the next W are warm-up, the next K are THE TIMED
 REGION of bench.py: the table holds, per launch of the plan, the median duration over those K forwards,
 its algorithmic FLOPs and bytes (from bench.py --dump-ops), and the fabric traffic of the PMC passes
-(FETCH_SIZE x 2 per MI355X_MICROARCH.md section HBM, + WRITE_SIZE; KiB -> bytes).
+(FETCH_SIZE x 2 per MI355X_MICROARCH.md section HBM, + WRITE_SIZE; KiB -> bytes).  The mfma pass adds the
+matrix pipes' utilisation by hardware counters, rocprofiler-sdk's MfmaUtil for gfx950:
+SQ_VALU_MFMA_BUSY_CYCLES (summed over the SIMDs: MFMA count x cycles per MFMA) / (GRBM_GUI_ACTIVE per XCD x 1024
+SIMDs), i.e. the share of the launch's shader cycles in which a SIMD's matrix pipe is busy, and the shader clock
+the launch ran at (GRBM_GUI_ACTIVE per XCD / its duration in that pass: reads high on launches under 0.3 ms).
 """
 import argparse
 import csv
@@ -81,18 +86,24 @@ def main():
     dur = [[(int(f[k]["End_Timestamp"]) - int(f[k]["Start_Timestamp"])) / 1e3 for f in timed] for k in range(nops)]
     wall = [(int(f[-1]["End_Timestamp"]) - int(f[0]["Start_Timestamp"])) / 1e3 for f in timed]
 
-    def pmc(kind):
+    def pmc(kind, counter=None, scale=1024.0, with_duration=False):
         g = glob.glob(os.path.join(a.prof, kind, "**", "*counter_collection.csv"), recursive=True)
         if not g:
             return None
-        rows = [r for r in csv.DictReader(open(g[0])) if "nbc::" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(g[0])) if "nbc::" in r["Kernel_Name"] and (counter is None or r["Counter_Name"] == counter)]
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         f = forwards(rows, nops)[first:first + a.steps]
         if not f:
             return None
-        return [statistics.median(float(x[k]["Counter_Value"]) for x in f) * 1024.0 for k in range(nops)]
+        vals = [statistics.median(float(x[k]["Counter_Value"]) for x in f) * scale for k in range(nops)]
+        if with_duration:
+            return vals, [statistics.median((int(x[k]["End_Timestamp"]) - int(x[k]["Start_Timestamp"])) / 1e3 for x in f) for k in range(nops)]
+        return vals
 
     fetch, write = pmc("fetch"), pmc("write")
+    busy = pmc("mfma", "SQ_VALU_MFMA_BUSY_CYCLES", 1.0)
+    gui = pmc("mfma", "GRBM_GUI_ACTIVE", 1.0, with_duration=True)
+    SIMDS, XCDS = 1024, 8
     peak = PEAK[a.precision]
     table = []
     for k, o in enumerate(ops):
@@ -107,6 +118,12 @@ def main():
             row["fetch_x2_bytes"] = fetch[k] * 2.0
             row["write_bytes"] = write[k]
             row["traffic_over_algorithmic"] = round((fetch[k] * 2.0 + write[k]) / o["bytes"], 2) if o["bytes"] else None
+        if busy and gui and gui[0][k] > 0:
+            cyc = gui[0][k] / XCDS                       # shader cycles of the launch (rocprofv3 sums the 8 XCDs)
+            row["mfma_busy_cycles"] = busy[k]
+            row["shader_cycles"] = round(cyc, 0)
+            row["mfma_util"] = round(busy[k] / (cyc * SIMDS), 4)
+            row["clock_ghz_in_pmc_pass"] = round(cyc / gui[1][k] / 1e3, 3)
         table.append(row)
 
     def agg(rows):
@@ -118,6 +135,8 @@ def main():
         if fetch and write:
             d["traffic_bytes"] = sum(r["fetch_x2_bytes"] + r["write_bytes"] for r in rows)
             d["algorithmic_bytes"] = sum(r["algorithmic_bytes"] for r in rows)
+        if busy and gui and all("mfma_util" in r for r in rows) and rows:
+            d["mfma_util"] = round(sum(r["mfma_busy_cycles"] for r in rows) / (sum(r["shader_cycles"] for r in rows) * SIMDS), 4)
         return d
 
     conv = [r for r in table if "conv_dma_kernel" in r["kernel"] or "conv_igemm" in r["kernel"]]

@@ -5,7 +5,8 @@
 #   1. a plain bench run measures the per-layer tiles once and saves them (tiles.json);
 #   2. rocprofv3 --kernel-trace --stats of the SAME bench command with those tiles installed, so that the
 #      trace and the --stats summary hold nothing but warm-up and timed forwards (no autotune launches);
-#   3. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (they do not fit one pass: MI355X_MICROARCH.md);
+#   3. FETCH_SIZE and WRITE_SIZE in separate --pmc passes (they do not fit one pass: MI355X_MICROARCH.md), and
+#      SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE in a third (matrix-pipe utilisation and shader clock per launch);
 #   4. scripts/per_forward_table.py -> per_forward_ops_<dtype>_b<batch>.json (copy it into profiles/).
 set -e
 root=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -22,11 +23,12 @@ for cfg in "fp32 1 f32" "bf16 8 bf16"; do
   echo "trace $cfg done"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 $root/bench.py $common --no-op-events > $d/fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 $root/bench.py $common --no-op-events > $d/write.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $d/mfma -- python3 $root/bench.py $common --no-op-events > $d/mfma.log 2>&1
   echo "pmc $cfg done"
   python3 $root/scripts/per_forward_table.py $d $out/per_forward_ops_${dt}_b${batch}.json --precision $prec --batch $batch --steps $K --warmup $W --no-autotune > $out/table_${dt}_b${batch}.log 2>&1 || { tail -5 $out/table_${dt}_b${batch}.log; exit 1; }
   cp $(find $d/trace -name "*kernel_stats.csv" | head -1) $out/rocprof_kernel_stats_${dt}_b${batch}.csv
   grep -h '"metric"' $d/trace.log > $out/bench_under_rocprof_${dt}_b${batch}.json || true
-  rm -rf $d/fetch $d/write          # counter CSVs are large; the table keeps what is needed
+  rm -rf $d/fetch $d/write $d/mfma  # counter CSVs are large; the table keeps what is needed
   find $d/trace -name "*kernel_trace.csv" -exec gzip -9 {} \;
 done
 head -40 $out/table_f32_b1.log
