@@ -327,6 +327,10 @@ def main():
                 out["traffic"] = t["dominant_kernel"]["traffic_bytes_per_launch"]
                 out["traffic_note"] = ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch of the dominant kernel (separate PMC passes, "
                                        "L2-miss traffic incl. Infinity-Cache hits), from profiles/%s" % os.path.basename(path))
+                if "mfma_util" in t["dominant_kernel"]:     # matrix-pipe utilisation by hardware counters, same table
+                    out["mfma_util_by_counters"] = t["dominant_kernel"]["mfma_util"]
+                    out["mfma_util_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs) over the dominant kernel's launches "
+                                             "(rocprofiler-sdk's MfmaUtil; busy cycles per shader cycle at the clock the launches ran at)")
             else:
                 out["traffic_note"] = "profiles/%s was measured for another batch / precision / kernel source: not quoted" % os.path.basename(path)
         except (OSError, KeyError, ValueError):
