@@ -330,7 +330,8 @@ def main():
                 if "mfma_util" in t["dominant_kernel"]:     # matrix-pipe utilisation by hardware counters, same table
                     out["mfma_util_by_counters"] = t["dominant_kernel"]["mfma_util"]
                     out["mfma_util_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs) over the dominant kernel's launches "
-                                             "(rocprofiler-sdk's MfmaUtil; busy cycles per shader cycle at the clock the launches ran at)")
+                                             "(rocprofiler-sdk's MfmaUtil: busy cycles per shader cycle at the clock the launches ran at; GRBM_GUI_ACTIVE over-counts on launches "
+                                             "under 0.3 ms, so the figure reads low against FLOPs over time there; the head conv alone: see the table)")
             else:
                 out["traffic_note"] = "profiles/%s was measured for another batch / precision / kernel source: not quoted" % os.path.basename(path)
         except (OSError, KeyError, ValueError):
