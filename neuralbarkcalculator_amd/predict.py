@@ -26,7 +26,7 @@ from __future__ import annotations
 import argparse
 import csv
 import os
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -175,21 +175,31 @@ def preprocess_image(img_u8: np.ndarray, target_size: int = 1024, model=None) ->
     return _float_to_u8(image)
 
 
-def _decode_bmp24(buf: bytes):
-    """Uncompressed 24-bit BMP (what the scanner writes, predict.py:15-17) straight into an RGB array: three
-    strided numpy copies (which drop the GIL) instead of PIL's decoder loop; None for any other flavour."""
+def _bmp24_layout(head: bytes, size: int):
+    """(pixel offset, width, rows, row stride, bottom_up) of an uncompressed 24-bit BMP from its first 54 bytes and
+    the file size; None for any other flavour."""
     import struct
-    if len(buf) < 54 or buf[:2] != b"BM":
+    if len(head) < 54 or head[:2] != b"BM":
         return None
-    off, = struct.unpack_from("<I", buf, 10)
-    hdr, w, h, planes, bpp, comp = struct.unpack_from("<IiiHHI", buf, 14)
+    off, = struct.unpack_from("<I", head, 10)
+    hdr, w, h, planes, bpp, comp = struct.unpack_from("<IiiHHI", head, 14)
     if hdr < 40 or planes != 1 or bpp != 24 or comp != 0 or w <= 0 or h == 0:
         return None
     rows, stride = abs(h), (w * 3 + 3) & ~3
-    if off + stride * rows > len(buf):
+    if off + stride * rows > size:
         return None
+    return off, w, rows, stride, h > 0
+
+
+def _decode_bmp24(buf: bytes):
+    """Uncompressed 24-bit BMP (what the scanner writes, predict.py:15-17) straight into an RGB array: three
+    strided numpy copies (which drop the GIL) instead of PIL's decoder loop; None for any other flavour."""
+    lay = _bmp24_layout(buf[:54], len(buf))
+    if lay is None:
+        return None
+    off, w, rows, stride, bottom_up = lay
     a = np.frombuffer(buf, np.uint8, stride * rows, off).reshape(rows, stride)[:, : w * 3].reshape(rows, w, 3)
-    if h > 0:
+    if bottom_up:
         a = a[::-1]                                  # bottom-up rows
     out = np.empty((rows, w, 3), dtype=np.uint8)
     out[..., 0], out[..., 1], out[..., 2] = a[..., 2], a[..., 1], a[..., 0]     # BGR -> RGB
@@ -206,6 +216,45 @@ def _decode_rgb(path: str) -> np.ndarray:
     if img is None:
         img = np.array(Image.open(io.BytesIO(buf)).convert("RGB"))
     return img
+
+
+_pinned = None          # threading.local: one pinned read buffer per pool thread (allocated on first use, grown on demand)
+
+
+def preprocess_bmp_scan_on_device(path: str, target_size: int, model, lock) -> Optional[np.ndarray]:
+    """models.py:173-203 for one raw scan that needs the resize, without touching its pixels on the host: the file
+    is read straight into pinned memory, the pixel array goes to the device as the scanner stored it (BGR,
+    bottom-up, padded rows), is put into RGB top-down order there and runs through ``nbc_preprocess_u8``; only the
+    1024 x 1024 result comes back.  Same bytes as ``preprocess_image(_decode_rgb(path), target_size, model)``; a
+    4096 x 4096 scan takes 20-30 ms of a pool thread instead of 150.  None when the file is not an uncompressed
+    24-bit BMP or is small enough to need no resize (the caller then takes the host route)."""
+    import threading
+    import torch
+    global _pinned
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        lay = _bmp24_layout(f.read(54), size)
+        if lay is None or max(lay[1], lay[2]) <= target_size:
+            return None
+        off, w, rows, stride, bottom_up = lay
+        if _pinned is None:
+            _pinned = threading.local()
+        buf = getattr(_pinned, "buf", None)
+        if buf is None or buf.numel() < size:
+            buf = _pinned.buf = torch.empty(size + (size >> 3), dtype=torch.uint8).pin_memory()
+        f.seek(0)
+        if f.readinto(buf.numpy()[:size]) != size:
+            return None
+    with lock:                                       # one context, one stream: device work of the pool is serialised
+        raw = buf[off: off + stride * rows].to(model.device, non_blocking=True)
+        img = raw.view(rows, stride)[:, : w * 3].reshape(rows, w, 3)
+        if bottom_up:
+            img = img.flip(0)
+        img = img.flip(2).contiguous()               # BGR -> RGB
+        out_dev, lit_dev = model.preprocess_u8(img, target_size, target_size)
+        out, lit = out_dev.cpu().numpy(), lit_dev.cpu().numpy()      # .cpu() waits for the stream: buf is free again
+    first, last = _trim_rows(lit / np.float64(target_size) > 0.85)
+    return np.ascontiguousarray(out[first:last])
 
 
 def _host_workers() -> int:
@@ -229,12 +278,14 @@ def preprocess_images(root: str, target_size: int = 1024, model=None) -> None:
 
     def one(item):
         path, name, wood = item
-        img = _decode_rgb(path)
-        if model is not None and max(img.shape[:2]) > target_size:
-            with lock:
-                out = preprocess_image(img, target_size, model)
-        else:
-            out = preprocess_image(img, target_size)
+        out = preprocess_bmp_scan_on_device(path, target_size, model, lock) if model is not None else None
+        if out is None:
+            img = _decode_rgb(path)
+            if model is not None and max(img.shape[:2]) > target_size:
+                with lock:
+                    out = preprocess_image(img, target_size, model)
+            else:
+                out = preprocess_image(img, target_size)
         write_png(os.path.join(root, "processed", "samples", wood, name), out, _png_level("processed"))
 
     with ThreadPoolExecutor(max_workers=_host_workers()) as pool:
@@ -415,14 +466,17 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         t0 = clock()
         if d["src"] is None:
             return _decode_rgb(d["processed"])
-        img = _decode_rgb(d["src"])
-        t1 = clock()
-        if max(img.shape[:2]) > target_size:
-            with resize_lock:
-                out = preprocess_image(img, target_size, pre_model)
-        else:
-            out = preprocess_image(img, target_size)
-        t2 = clock()
+        out = preprocess_bmp_scan_on_device(d["src"], target_size, pre_model, resize_lock)     # raw scans: no host decode
+        t1 = t2 = clock()
+        if out is None:
+            img = _decode_rgb(d["src"])
+            t1 = clock()
+            if max(img.shape[:2]) > target_size:
+                with resize_lock:
+                    out = preprocess_image(img, target_size, pre_model)
+            else:
+                out = preprocess_image(img, target_size)
+            t2 = clock()
         write_png(d["processed"], out, lvl_proc)
         t3 = clock()
         prof["pool.decode"] += t1 - t0; prof["pool.preprocess"] += t2 - t1; prof["pool.write_processed"] += t3 - t2

@@ -4,6 +4,8 @@ folder of 1024x1024 .bmp samples -> decode, preprocess, processed/ PNG, forward 
 PNG, CSV.  usage: python scripts/time_folder.py [n_images=1000] [precisions=bf16,fp32] [ragged]
 "ragged": every scan has black bands at the top and bottom, so that trim_black leaves heights of 520-730 rows (what
 the reference's real folders look like: res/*.png): hundreds of distinct image shapes in one folder.
+"raw": raw scans of 4096x4096 pixels with the same black bands (48 MB per .bmp): the whole preprocessor runs (cubic
+resize to 1024x1024 on the GPU, trim_black, processed/ PNG) before the forward.
 NBC_HOST_WORKERS sets the host thread pool (default 16, the GPU box's CPU share per GPU)."""
 import json
 import os
@@ -21,7 +23,8 @@ from neuralbarkcalculator_amd import predict as drv, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 precisions = (sys.argv[2] if len(sys.argv) > 2 else "bf16,fp32").split(",")
-ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
+raw = len(sys.argv) > 3 and sys.argv[3] == "raw"
+ragged = raw or (len(sys.argv) > 3 and sys.argv[3] == "ragged")
 distinct = min(n, 40)
 root = tempfile.mkdtemp(prefix="nbc_folder_")
 try:
@@ -41,12 +44,14 @@ try:
             top = (i * 13) % (band + 1)
             g[:top] = 0
             g[1024 - (band - top):] = 0
+            if raw:
+                g = np.repeat(np.repeat(g, 4, axis=0), 4, axis=1)
             return g
         list(pool.map(lambda i: Image.fromarray(scan(i), mode="RGB").save(
             os.path.join(root, "samples", woods[i % 3], "f%04d.bmp" % i)), range(n)))
     ckpt = os.path.join(root, "best_model.pt")
     torch.save({k: torch.from_numpy(v) for k, v in synth.make_state_dict("trained_like", seed=7).items()}, ckpt)
-    print(f"folder of {n} synthetic 1024x1024 .bmp samples ({distinct} distinct frames{', black bands: 520-730 rows after trim_black' if ragged else ''}) made in {time.perf_counter() - t0:.1f} s; "
+    print(f"folder of {n} synthetic {'4096x4096' if raw else '1024x1024'} .bmp samples ({distinct} distinct frames{', black bands: 520-730 rows after trim_black' if ragged else ''}) made in {time.perf_counter() - t0:.1f} s; "
           f"host workers {drv._host_workers()}, cores available {len(os.sched_getaffinity(0))}", flush=True)
     for prec in precisions:
         for rep in range(2):                  # second run: page cache and allocator warm

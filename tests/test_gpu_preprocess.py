@@ -72,3 +72,44 @@ def test_device_quantisation_and_lit_counts(model):
     a = drv.preprocess_image(img[:, :1100][:1100], 512)
     b = drv.preprocess_image(img[:, :1100][:1100], 512, model)
     assert a.shape == b.shape and a.shape[0] < 512 and np.array_equal(a, b)
+
+
+def _write_bmp24(path, img, top_down):
+    """A 24-bit uncompressed BMP by hand: rows padded to 4 bytes, BGR, bottom-up unless ``top_down`` (negative height)."""
+    import struct
+    h, w = img.shape[:2]
+    stride = (w * 3 + 3) & ~3
+    rows = np.zeros((h, stride), dtype=np.uint8)
+    rows[:, : w * 3] = img[..., ::-1].reshape(h, w * 3)
+    if not top_down:
+        rows = rows[::-1]
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + stride * h, 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, 24, 0, stride * h, 2835, 2835, 0, 0))
+        f.write(np.ascontiguousarray(rows).tobytes())
+
+
+@pytest.mark.parametrize("shape,top_down", [((1500, 1301), False), ((1301, 1500), True), ((2048, 2048), False)])
+def test_raw_bmp_scan_through_the_device_equals_the_host_decode(tmp_path, model, shape, top_down):
+    """The raw-scan route of the folder driver (file -> pinned memory -> device, BGR / bottom-up / padded rows put in
+    order there) writes the bytes the host-decode route writes, including a square scan that trim_black cuts."""
+    import threading
+    rng = np.random.default_rng(shape[0] + shape[1])
+    img = rng.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+    img[: shape[0] // 5] = 0                                      # a black band (cut by trim_black when the scan is square)
+    path = str(tmp_path / "scan.bmp")
+    _write_bmp24(path, img, top_down)
+    assert np.array_equal(drv._decode_rgb(path), img)             # the host decoder reads the hand-written file
+    want = drv.preprocess_image(img, 1024, model)
+    got = drv.preprocess_bmp_scan_on_device(path, 1024, model, threading.Lock())
+    assert got is not None and got.dtype == np.uint8 and np.array_equal(got, want)
+    if shape[0] == shape[1]:
+        assert got.shape[0] < 1024                                # trimmed
+    # small images and other formats take the host route
+    small = str(tmp_path / "small.bmp")
+    _write_bmp24(small, img[:600, :700], False)
+    assert drv.preprocess_bmp_scan_on_device(small, 1024, model, threading.Lock()) is None
+    from PIL import Image
+    png = str(tmp_path / "scan.png")
+    Image.fromarray(img).save(png)
+    assert drv.preprocess_bmp_scan_on_device(png, 1024, model, threading.Lock()) is None
