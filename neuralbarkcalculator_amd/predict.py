@@ -637,12 +637,13 @@ def main(argv=None):
                     help="measure the conv tile shapes once per distinct full-batch image shape (0.5-0.9 s each) instead of the default choice")
     raw = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(raw)
-    if args.only_preprocess:
-        generate_folders(args.root_path, True)
-        preprocess_images(args.root_path)
-        return
     if not args.device.startswith("cuda"):
         raise SystemExit("this package is the MI355X path; run the reference for --device=cpu")
+    if args.only_preprocess:                             # predict.py:53-55: the resize runs on the device here too
+        from .model import FCNResNet50
+        generate_folders(args.root_path, True)
+        preprocess_images(args.root_path, model=FCNResNet50(args.precision).to(args.device))   # no weights needed
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, raw))
     idx = None

@@ -163,3 +163,29 @@ def test_two_rank_folder_rehearsal_on_one_gpu(tmp_path, sd_np, built_lib):
     assert outs[0][1] == outs[1][1] and len(outs[0][0]) == 10 and outs[0][0].keys() == outs[1][0].keys()
     for k in outs[0][0]:
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+
+
+def test_only_preprocess_cli_writes_what_the_numpy_form_writes(tmp_path, built_lib):
+    """`predict.py --only_preprocess` (predict.py:53-55): raw scans larger than 1024 are resized on the device; the
+    processed PNGs hold the bytes of the numpy restatement (itself pinned to scikit-image's output by the fixtures)."""
+    import subprocess
+    import sys
+    root = str(tmp_path / "raw")
+    os.makedirs(os.path.join(root, "samples", "sapin"))
+    rng = np.random.default_rng(5)
+    big = rng.integers(0, 256, size=(1300, 1500, 3), dtype=np.uint8)
+    square = rng.integers(0, 256, size=(1200, 1200, 3), dtype=np.uint8)
+    square[:300] = 0                                           # cut by trim_black
+    small = synth.make_frame(3, 200, 320)
+    for name, img in (("big.bmp", big), ("square.bmp", square), ("small.bmp", small)):
+        Image.fromarray(img, mode="RGB").save(os.path.join(root, "samples", "sapin", name))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", root, "--only_preprocess"],
+                       cwd=repo, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert not os.path.exists(os.path.join(root, "results"))
+    for name, img in (("big.png", big), ("square.png", square), ("small.png", small)):
+        got = np.asarray(Image.open(os.path.join(root, "processed", "samples", "sapin", name)))
+        want = drv.preprocess_image(img, 1024)
+        assert got.shape == want.shape and np.array_equal(got, want), name
+    assert np.asarray(Image.open(os.path.join(root, "processed", "samples", "sapin", "square.png"))).shape[0] < 1024
