@@ -391,6 +391,29 @@ def test_ragged_shapes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, shape):
         assert torch.equal(counts.cpu().sum(dim=1), torch.full((n,), h * w, dtype=torch.int64))
 
 
+@pytest.mark.parametrize("n,h", [(1, 624), (2, 528)])
+def test_trimmed_scan_sizes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, n, h):
+    """The sizes real folders hold after trim_black (520-730 rows of 1024 pixels), where the cost model picks other
+    tiles than at 1024 rows (three 64x128 blocks per CU on the head conv, ...): full-resolution logits and labels
+    against the oracle, f32 labels identical outside the tie band."""
+    x = frames(range(70, 70 + n), h, 1024)
+    labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
+    scale = float(logits_ref.abs().max())
+    xd = x.to(DEV)
+    labels, counts = gpu_fp32.predict_labels(xd)
+    logits = gpu_fp32(xd)
+    torch.cuda.synchronize()
+    err = float((logits.cpu() - logits_ref).abs().max())
+    assert err <= LOGIT_RTOL_FP32 * scale, (err, scale)
+    flips = check_labels(labels, labels_ref, logits_ref, err)
+    assert torch.equal(labels, torch.argmax(logits, 1))
+    assert torch.equal(counts.cpu().sum(dim=1), torch.full((n,), h * 1024, dtype=torch.int64))
+    lb, cb = gpu_bf16.predict_labels(xd)
+    agree = float((lb.cpu() == labels_ref).float().mean())
+    assert agree >= 0.98, agree
+    print("%d x %dx1024: f32 max logit error %.2e of range %.2f, %d label flips; bf16 agreement %.5f" % (n, h, err, scale, flips, agree))
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_overlapped_forwards_on_four_streams(gpu_fp32, gpu_bf16, mode):
     """bench.py's default: four model objects sharing one packed weight blob (`clone_shared`), each
