@@ -391,6 +391,32 @@ def test_ragged_shapes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, shape):
         assert torch.equal(counts.cpu().sum(dim=1), torch.full((n,), h * w, dtype=torch.int64))
 
 
+def test_random_small_shapes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16):
+    """Thirty (N, H, W) drawn at random from 8..160 (plus the extremes): whatever tile the cost model picks for
+    however few pixels, partial tiles everywhere; f32 logits and labels against the oracle, bf16 within its band."""
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 8, 8), (1, 8, 160), (1, 160, 8), (4, 16, 16), (1, 15, 17)]
+    shapes += [(int(rng.integers(1, 4)), int(rng.integers(8, 161)), int(rng.integers(8, 161))) for _ in range(25)]
+    worst = 0.0
+    for k, (n, h, w) in enumerate(shapes):
+        x = frames(range(100 + k, 100 + k + n), h, w)
+        labels_ref, counts_ref, logits_ref, lowres_ref = oracle_run(oracle_model, x)
+        scale = float(logits_ref.abs().max())
+        xd = x.to(DEV)
+        labels, counts = gpu_fp32.predict_labels(xd)
+        logits = gpu_fp32(xd)
+        err = float((logits.cpu() - logits_ref).abs().max())
+        assert err <= LOGIT_RTOL_FP32 * scale, ((n, h, w), err, scale)
+        check_labels(labels, labels_ref, logits_ref, err)
+        assert torch.equal(counts.cpu().sum(dim=1), torch.full((n,), h * w, dtype=torch.int64))
+        worst = max(worst, err / scale)
+        lb, _ = gpu_bf16.predict_labels(xd)
+        lgb = gpu_bf16(xd)
+        assert float((lgb.cpu() - logits_ref).abs().max()) <= LOGIT_RTOL_BF16 * scale, (n, h, w)
+        assert float((lb.cpu() == labels_ref).float().mean()) >= 0.95, (n, h, w)
+    print("30 random shapes: worst f32 logit error %.2e of the logit range" % worst)
+
+
 @pytest.mark.parametrize("n,h", [(1, 624), (2, 528)])
 def test_trimmed_scan_sizes_vs_oracle(oracle_model, gpu_fp32, gpu_bf16, n, h):
     """The sizes real folders hold after trim_black (520-730 rows of 1024 pixels), where the cost model picks other
