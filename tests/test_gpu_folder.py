@@ -189,3 +189,24 @@ def test_only_preprocess_cli_writes_what_the_numpy_form_writes(tmp_path, built_l
         want = drv.preprocess_image(img, 1024)
         assert got.shape == want.shape and np.array_equal(got, want), name
     assert np.asarray(Image.open(os.path.join(root, "processed", "samples", "sapin", "square.png"))).shape[0] < 1024
+
+
+def test_empty_and_single_image_folders(tmp_path, sd_np, built_lib):
+    """Edge cases of the driver (the reference walks whatever samples/ holds): a wood-type folder with no image
+    at all gives a CSV with only the header; a single image gives one row; files that are not images are ignored."""
+    root = str(tmp_path / "empty")
+    os.makedirs(os.path.join(root, "samples", "sapin"))
+    ckpt = os.path.join(root, "best_model.pt")
+    torch.save({k: torch.from_numpy(v) for k, v in sd_np.items()}, ckpt)
+    open(os.path.join(root, "samples", "sapin", "notes.txt"), "w").write("not an image")
+    st = drv.predict_folder(root, ckpt, device_index=0)
+    assert st["images_total"] == 0 and st["batches"] == 0
+    lines = open(os.path.join(root, "results", "final_stats.csv")).read().strip().splitlines()
+    assert len(lines) == 1
+    Image.fromarray(synth.make_frame(9, 72, 96), mode="RGB").save(os.path.join(root, "samples", "sapin", "one.bmp"))
+    st = drv.predict_folder(root, ckpt, device_index=0)
+    assert st["images_total"] == 1 and st["batches"] == 1
+    lines = open(os.path.join(root, "results", "final_stats.csv")).read().strip().splitlines()
+    assert len(lines) == 2 and lines[1].startswith("one.png\tsapin\t")
+    lab = np.asarray(Image.open(os.path.join(root, "results", "outputs", "sapin", "one.png")))
+    assert lab.shape == (72, 96) and set(np.unique(lab).tolist()) <= {0, 127, 255}
