@@ -145,6 +145,12 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE %d: refusing to print a line for another job size"
                   % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    # stdout carries rank 0's ONE JSON line and nothing else: whatever the libraries print on it while they load,
+    # connect or run (gloo announces its peers, RCCL its version) goes to stderr; the line is written to the saved
+    # descriptor at the very end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     dist = None
     setup = {}
     t0 = time.perf_counter()
@@ -156,20 +162,11 @@ def main():
             local_rank = 0
             args.dist_backend = "gloo"
         torch.cuda.set_device(local_rank)
-        # stdout carries rank 0's ONE JSON line and nothing else: whatever the communication libraries print
-        # while they connect (gloo announces its peers on stdout) goes to stderr
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            if args.dist_backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            else:
-                dist.init_process_group(args.dist_backend)
-            dist.barrier()
-        finally:
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
+        dist.barrier()
         setup["process_group_init_s"] = time.perf_counter() - t0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -481,7 +478,9 @@ def main():
         if world == 1 and not args.no_parity:
             o8["parity"] = parity_of(leg8["model"], [0, 1], 8)
         out["bf16_batch8"] = o8
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(line_fd, (json.dumps(out) + "\n").encode())
+    os.close(line_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
