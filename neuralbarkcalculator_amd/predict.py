@@ -26,6 +26,7 @@ from __future__ import annotations
 import argparse
 import csv
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -218,7 +219,7 @@ def _decode_rgb(path: str) -> np.ndarray:
     return img
 
 
-_pinned = None          # threading.local: one pinned read buffer per pool thread (allocated on first use, grown on demand)
+_pinned = threading.local()      # one pinned read buffer per pool thread (allocated on first use, grown on demand)
 
 
 def preprocess_bmp_scan_on_device(path: str, target_size: int, model, lock) -> Optional[np.ndarray]:
@@ -228,17 +229,13 @@ def preprocess_bmp_scan_on_device(path: str, target_size: int, model, lock) -> O
     1024 x 1024 result comes back.  Same bytes as ``preprocess_image(_decode_rgb(path), target_size, model)``; a
     4096 x 4096 scan takes 20-30 ms of a pool thread instead of 150.  None when the file is not an uncompressed
     24-bit BMP or is small enough to need no resize (the caller then takes the host route)."""
-    import threading
     import torch
-    global _pinned
     size = os.path.getsize(path)
     with open(path, "rb") as f:
         lay = _bmp24_layout(f.read(54), size)
         if lay is None or max(lay[1], lay[2]) <= target_size:
             return None
         off, w, rows, stride, bottom_up = lay
-        if _pinned is None:
-            _pinned = threading.local()
         buf = getattr(_pinned, "buf", None)
         if buf is None or buf.numel() < size:
             buf = _pinned.buf = torch.empty(size + (size >> 3), dtype=torch.uint8).pin_memory()
