@@ -132,7 +132,9 @@ int nbc_load_weights(nbc_ctx* ctx, const nbc_tensor* tensors, int n, int precisi
 int nbc_bcast_weights(nbc_ctx* ctx, void* rccl_comm, int root, int precision, void* hip_stream);
 /* mean/std used for NBC_IN_U8_NHWC input; defaults are models.py:208-209. */
 int nbc_set_normalization(nbc_ctx* ctx, const float mean[3], const float std[3]);
-/* Pre-size the workspace for an (N,H,W) so that the first nbc_forward does not allocate. */
+/* Pre-size the workspace for an (N,H,W) so that the first nbc_forward does not allocate.  Buffers only grow, and a
+ * growth frees and reallocates (which synchronises the device): a caller that will see many shapes reserves the
+ * largest one first, as the folder driver does. */
 int nbc_reserve(nbc_ctx* ctx, int N, int H, int W);
 
 /* ---- the hot path ------------------------------------------------------------------------

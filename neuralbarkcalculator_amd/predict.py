@@ -435,6 +435,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     models = [model] + [model.clone_shared() for _ in range(n_streams - 1)]
     # side streams only: the default stream stays with the pool's device resizes (pre_model)
     gpu_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    for m in models:                                 # the largest workspace once: a context's buffers only grow, and a folder of
+        m.reserve(batch, target_size, target_size)   # rising heights would otherwise free and reallocate them shape after shape
     torch.cuda.synchronize(dev)                      # weights uploaded / received before any side stream reads them
     t_ready = time.perf_counter()
 
@@ -488,10 +490,14 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         prof["pool.write_labels"] += clock() - t0
 
     # pinned rings, one slot more than batches in flight: frames going up, labels + counts coming back
+    # (allocated once for the largest batch: pinning memory costs milliseconds, and a folder of rising heights would
+    # otherwise re-pin at every new shape)
     depth = n_streams + 1
-    ring = [None] * depth
+    full = batch * target_size * target_size
+    ring = [(torch.empty(full, dtype=torch.uint8).pin_memory(), torch.empty((batch, 3), dtype=torch.int64).pin_memory())
+            for _ in range(depth)]
     ring_ev = [torch.cuda.Event() for _ in range(depth)]
-    stage = [{"buf": None, "ev": torch.cuda.Event()} for _ in range(depth)]
+    stage = [{"buf": torch.empty(full * 3, dtype=torch.uint8).pin_memory(), "ev": torch.cuda.Event()} for _ in range(depth)]
     pending = deque()                                # (slot, [(k, gi)], n, h, w), oldest first
     done = []
     tuned = set()
@@ -536,17 +542,16 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
                     sid = n_batches % n_streams
                     mdl = models[sid]
                     st = stage[slot]                          # frames are packed while the GPU runs the batches before
-                    if st["buf"] is None or st["buf"].numel() < n * h * w * 3:
-                        st["buf"] = torch.empty(max(n, batch) * h * w * 3, dtype=torch.uint8).pin_memory()
+                    if st["buf"].numel() < n * h * w * 3:       # cannot happen after the preprocessor (h, w <= target_size)
+                        st["buf"] = torch.empty(n * h * w * 3, dtype=torch.uint8).pin_memory()
                     st["ev"].synchronize()                    # the copy that last read this buffer has finished
                     xb = st["buf"][: n * h * w * 3].view(n, h, w, 3)
                     xnp = xb.numpy()
                     for j, k in enumerate(part):
                         xnp[j] = frames[k]
                     need = n * h * w
-                    if ring[slot] is None or ring[slot][0].numel() < need or ring[slot][1].shape[0] < n:
-                        ring[slot] = (torch.empty(max(need, batch * h * w), dtype=torch.uint8).pin_memory(),
-                                      torch.empty((max(n, batch), 3), dtype=torch.int64).pin_memory())
+                    if ring[slot][0].numel() < need or ring[slot][1].shape[0] < n:
+                        ring[slot] = (torch.empty(need, dtype=torch.uint8).pin_memory(), torch.empty((n, 3), dtype=torch.int64).pin_memory())
                     t1 = clock()
                     with torch.cuda.stream(gpu_streams[sid]):
                         x = xb.to(dev, non_blocking=True)     # uint8 NHWC; normalised on the device

@@ -58,7 +58,7 @@ try:
             shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
             shutil.rmtree(os.path.join(root, "processed"), ignore_errors=True)
             t0 = time.perf_counter()
-            st = drv.predict_folder(root, ckpt, precision=prec, device_index=0)
+            st = drv.predict_folder(root, ckpt, precision=prec, device_index=0, window=int(os.environ.get("NBC_WINDOW", "64")))
             dt = time.perf_counter() - t0
             rows = open(os.path.join(root, "results", "final_stats.csv")).read().count("\n") - 1
             print(f"{prec} run {rep}: {n} images end to end in {dt:.2f} s = {n / dt:.1f} images/s "
