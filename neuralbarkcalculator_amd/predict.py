@@ -437,6 +437,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     gpu_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     for m in models:                                 # the largest workspace once: a context's buffers only grow, and a folder of
         m.reserve(batch, target_size, target_size)   # rising heights would otherwise free and reallocate them shape after shape
+        if small_zones:                              # likewise the remove_small_zones workspace (9 bytes per pixel)
+            m.remove_small_zones(torch.zeros((batch, target_size, target_size), dtype=torch.uint8, device=dev))
     torch.cuda.synchronize(dev)                      # weights uploaded / received before any side stream reads them
     t_ready = time.perf_counter()
 
