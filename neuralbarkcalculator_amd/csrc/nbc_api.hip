@@ -217,17 +217,26 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
 }
 
 // Workspace of the current plan: buffers only ever grow, so a plan taken back from the cache finds
-// them large enough unless a later, smaller-indexed plan never needed that slot.
+// them large enough unless a later, smaller-indexed plan never needed that slot.  A buffer that has to grow
+// grows by at least half (hipFree synchronises the device: shapes that rise one after the other then reallocate
+// O(log) times, not once per shape); a caller that knows its largest shape reserves it first (nbc_reserve).
 int ensure_buffers(nbc_ctx* c) {
   const Plan& P = c->plan;
   if (c->bufs.size() < P.buf_bytes.size()) { c->bufs.resize(P.buf_bytes.size(), nullptr); c->buf_cap.resize(P.buf_bytes.size(), 0); }
   for (size_t i = 0; i < P.buf_bytes.size(); ++i) {
     if (c->buf_cap[i] < P.buf_bytes[i]) {
+      const size_t grown = c->buf_cap[i] + c->buf_cap[i] / 2;
       if (c->bufs[i]) NBC_HIP(hipFree(c->bufs[i]));
       c->bufs[i] = nullptr; c->buf_cap[i] = 0;
-      hipError_t e = hipMalloc(&c->bufs[i], P.buf_bytes[i]);
+      size_t want = std::max(P.buf_bytes[i], grown);
+      hipError_t e = hipMalloc(&c->bufs[i], want);
+      if (e != hipSuccess && want > P.buf_bytes[i]) {          // no room for the margin: the exact size
+        (void)hipGetLastError();
+        want = P.buf_bytes[i];
+        e = hipMalloc(&c->bufs[i], want);
+      }
       if (e != hipSuccess) return set_error(NBC_ERR_NOMEM, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
-      c->buf_cap[i] = P.buf_bytes[i];
+      c->buf_cap[i] = want;
     }
   }
   const size_t lr = (size_t)P.N * kNumClasses * P.h * P.w * sizeof(float);
@@ -668,10 +677,15 @@ int nbc_remove_small_zones(nbc_ctx* c, void* labels_dev, int labels_dtype, int N
   if (labels_dtype != NBC_LABEL_U8 && labels_dtype != NBC_LABEL_I64) return set_error(NBC_ERR_INVALID, "nbc_remove_small_zones: bad labels_dtype");
   NBC_HIP(hipSetDevice(c->device));
   const size_t px = (size_t)N * H * W;
-  if (px > c->zones_px) {
+  if (px > c->zones_px) {                             // grows by at least half, like the activation buffers
+    size_t cap = std::max(px, c->zones_px + c->zones_px / 2);
     if (c->zones_ws) { NBC_HIP(hipFree(c->zones_ws)); c->zones_ws = nullptr; c->zones_px = 0; }
-    NBC_HIP(hipMalloc(&c->zones_ws, px * 9 + 256));
-    c->zones_px = px;
+    if (hipMalloc(&c->zones_ws, cap * 9 + 256) != hipSuccess) {
+      (void)hipGetLastError();
+      cap = px;
+      NBC_HIP(hipMalloc(&c->zones_ws, cap * 9 + 256));
+    }
+    c->zones_px = cap;
   }
   int* parent = static_cast<int*>(c->zones_ws);
   int* size = parent + px;
