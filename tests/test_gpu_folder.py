@@ -211,3 +211,36 @@ def test_empty_and_single_image_folders(tmp_path, sd_np, built_lib):
     assert len(lines) == 2 and lines[1].startswith("one.png\tsapin\t")
     lab = np.asarray(Image.open(os.path.join(root, "results", "outputs", "sapin", "one.png")))
     assert lab.shape == (72, 96) and set(np.unique(lab).tolist()) <= {0, 127, 255}
+
+
+def test_predict_cli_matches_the_library_call(tmp_path, sd_np, built_lib):
+    """`python -m neuralbarkcalculator_amd.predict DIR --model_path ... --exclude_nodes` (the reference's
+    `predict.py DIR --exclude_nodes`) writes the files the library call writes."""
+    import subprocess
+    import sys
+    layout = [("sapin", "a.bmp", 11, 88, 120), ("sapin", "b.bmp", 12, 88, 120), ("epinette_gelee", "c.png", 13, 64, 200)]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for how in ("cli", "call"):
+        root = str(tmp_path / how)
+        ckpt, _ = _make_folder(root, sd_np, layout)
+        if how == "cli":
+            p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", root, "--model_path", ckpt, "--exclude_nodes",
+                                "--streams", "2"], cwd=repo, capture_output=True, text=True, timeout=600)
+            assert p.returncode == 0, p.stderr[-3000:]
+            assert "predicted 3 images" in p.stdout
+        else:
+            drv.predict_folder(root, ckpt, exclude_nodes=True, device_index=0, streams=2)
+        labs = {}
+        for wood in ("sapin", "epinette_gelee"):
+            d = os.path.join(root, "results", "outputs", wood)
+            for n in sorted(os.listdir(d)):
+                labs[(wood, n)] = np.asarray(Image.open(os.path.join(d, n)))
+        outs.append((labs, open(os.path.join(root, "results", "final_stats.csv")).read()))
+    assert outs[0][1] == outs[1][1] and outs[0][0].keys() == outs[1][0].keys() and len(outs[0][0]) == 3
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]) and set(np.unique(outs[0][0][k]).tolist()) <= {0, 127}      # --exclude_nodes: no 255
+    # the CPU device is the reference's own path
+    p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", str(tmp_path / "cli"), "--device", "cpu"],
+                       cwd=repo, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "MI355X" in (p.stderr + p.stdout)
