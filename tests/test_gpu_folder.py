@@ -244,3 +244,47 @@ def test_predict_cli_matches_the_library_call(tmp_path, sd_np, built_lib):
     p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", str(tmp_path / "cli"), "--device", "cpu"],
                        cwd=repo, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "MI355X" in (p.stderr + p.stdout)
+
+
+def test_mixed_folder_is_independent_of_batching_and_streams(tmp_path, sd_np, built_lib):
+    """Raw scans that need the device resize (two aspect ratios), height-trimmed 1024-wide scans and small images in
+    three file formats in one folder: every processed PNG, label PNG and the CSV are the same whether the driver runs
+    one image at a time on one stream or batches on several."""
+    import hashlib
+    import shutil
+    root = str(tmp_path / "mixed")
+    layout_small = [("sapin", "s%02d.%s" % (i, ("png", "jpg", "bmp")[i % 3]), 200 + i, 40 + 37 * i % 300, 64 + 53 * i % 500) for i in range(8)]
+    ckpt, _ = _make_folder(root, sd_np, layout_small)
+    for i in range(2):                                  # raw scans: 2048 x 2048 and 2048 x 1548
+        f = synth.make_frame(i, 1024, 1024)
+        f[: 100 + 40 * i] = 0
+        g = np.repeat(np.repeat(f, 2, axis=0), 2, axis=1)
+        if i == 1:
+            g = g[:, :1548]
+        Image.fromarray(np.ascontiguousarray(g), mode="RGB").save(os.path.join(root, "samples", "sapin", "raw%d.bmp" % i))
+    os.makedirs(os.path.join(root, "samples", "epinette_gelee"), exist_ok=True)
+    for i in range(5):                                  # 1024 x 1024 scans with black bands: trimmed to different heights
+        f = synth.make_frame(100 + i, 1024, 1024).copy()
+        f[: 150 + 30 * i] = 0
+        f[1024 - 200:] = 0
+        Image.fromarray(f, mode="RGB").save(os.path.join(root, "samples", "epinette_gelee", "t%d.bmp" % i))
+
+    def digest():
+        h = hashlib.sha256()
+        for sub in ("processed", "results"):
+            for d, _, files in sorted(os.walk(os.path.join(root, sub))):
+                for f in sorted(files):
+                    p = os.path.join(d, f)
+                    h.update(os.path.relpath(p, root).encode())
+                    h.update(np.asarray(Image.open(p)).tobytes() if f.endswith(".png") else open(p, "rb").read())
+        return h.hexdigest()
+    seen = set()
+    for kw in (dict(batch=1, streams=1), dict(batch=2, streams=4), dict(batch=4, streams=3, window=4)):
+        shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
+        shutil.rmtree(os.path.join(root, "processed"), ignore_errors=True)
+        st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0, **kw)
+        assert st["images_total"] == 15
+        seen.add(digest())
+    assert len(seen) == 1
+    heights = sorted(np.asarray(Image.open(os.path.join(root, "processed", "samples", "epinette_gelee", "t%d.png" % i))).shape[0] for i in range(5))
+    assert heights == [554, 584, 614, 644, 674]          # trim_black cut the bands
