@@ -254,3 +254,38 @@ def test_gpus_flag_refuses_more_ranks_than_gpus(tmp_path):
     p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", str(tmp_path), "--gpus", str(n)], cwd=root, env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and "--gpus %d" % n in p.stderr
+
+
+def test_bmp_header_fuzz_never_crashes(tmp_path):
+    """The fast BMP path sees whatever a folder holds: truncated files, absurd sizes, other flavours.  Every mutation
+    of a good header either decodes to an array of the declared size or is handed to PIL (None), never an exception
+    or an out-of-bounds read."""
+    import io
+    import struct
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(13, 21, 3), dtype=np.uint8)
+    good = io.BytesIO()
+    Image.fromarray(img, mode="RGB").save(good, format="BMP")
+    good = good.getvalue()
+    assert np.array_equal(drv._decode_bmp24(good), img)
+    for trial in range(400):
+        b = bytearray(good)
+        kind = trial % 5
+        if kind == 0:                                   # random header bytes
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, 54))] = int(rng.integers(0, 256))
+        elif kind == 1:                                 # truncated file
+            b = b[: int(rng.integers(0, len(b)))]
+        elif kind == 2:                                 # absurd width / height
+            struct.pack_into("<ii", b, 18, int(rng.integers(-2**31, 2**31 - 1)), int(rng.integers(-2**31, 2**31 - 1)))
+        elif kind == 3:                                 # pixel offset anywhere
+            struct.pack_into("<I", b, 10, int(rng.integers(0, 2**32 - 1)))
+        else:                                           # other bit depths / compression
+            struct.pack_into("<HHI", b, 26, int(rng.integers(0, 4)), int(rng.choice([1, 4, 8, 16, 24, 32])), int(rng.integers(0, 4)))
+        out = drv._decode_bmp24(bytes(b))
+        lay = drv._bmp24_layout(bytes(b[:54]), len(b))
+        assert (out is None) == (lay is None)
+        if out is not None:
+            off, w, rows, stride, _ = lay
+            assert out.shape == (rows, w, 3) and off + stride * rows <= len(b)
