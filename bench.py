@@ -58,7 +58,6 @@ def parse(argv=None):
                     help="independent forwards kept in flight on separate HIP streams (each its own workspace)")
     ap.add_argument("--weights", choices=["random_init", "trained_like"], default="trained_like")
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
-    ap.add_argument("--conv-impl", type=int, default=1, help="1 = LDS-DMA ring kernel (default), 0 = register-staged kernel")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0.. force a tile shape (A/B runs)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -211,13 +210,13 @@ def main():
             b = np.stack([frames[(i + j) % nf] for j in range(batch)])
             batches.append(torch.from_numpy(b).to(dev))
         model.reserve(batch, H, W)
-        model.set_conv_impl(args.conv_impl, args.conv_tile)
+        model.set_conv_tile(args.conv_tile)
         tiles = None
         key = "%s_b%d_s%d" % (precision, batch, nstreams)
         installed = None
         if args.tiles_file:
             installed = json.load(open(args.tiles_file))
-        tune = not args.no_autotune and args.conv_impl == 1 and args.conv_tile < 0 and installed is None
+        tune = not args.no_autotune and args.conv_tile < 0 and installed is None
         objective = "throughput" if nstreams > 1 else "latency"
         if tune:
             tiles = model.autotune(batches[0], objective=objective)   # setup: per-layer tile shape by measurement
@@ -228,7 +227,7 @@ def main():
         for _ in range(nstreams - 1):
             m2 = model.clone_shared()
             m2.reserve(batch, H, W)
-            m2.set_conv_impl(args.conv_impl, args.conv_tile)
+            m2.set_conv_tile(args.conv_tile)
             if tune:
                 m2.autotune(batches[0], objective=objective)
             elif installed is not None:
@@ -288,7 +287,7 @@ def main():
         prec = leg["precision"]
         records = leg["records"]
         steps = leg["steps"]
-        conv = [r for r in records if r["kernel"] == "conv_igemm"]
+        conv = [r for r in records if r["kernel"] == "conv_dma"]
         dom = [r for r in conv if r["cout"] % 128 == 0 and r["name"] != "backbone.conv1"]   # the wide-tile instantiations
         flops = sum(r["flops"] for r in dom)
         ms = sum(r["ms"] for r in dom)
@@ -394,7 +393,7 @@ def main():
                                "1024x1024x3 frames resident in HBM, forward + argmax + class counts"
                                % (cfg, args.batch, DTYPE_NAME[args.precision], args.weights),
                    "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank",
-                   "conv_impl": args.conv_impl, "conv_tile": args.conv_tile, "streams": head["nstreams"],
+                   "conv_tile": args.conv_tile, "streams": head["nstreams"],
                    "autotuned_tiles": head["tiles"]},
         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "dist_backend": (args.dist_backend if dist is not None else None),

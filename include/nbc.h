@@ -83,7 +83,7 @@ typedef struct {
 /* Per-launch record of the last profiled forward (nbc_set_profiling). */
 typedef struct {
   char name[64];      /* conv unit name, or "ingest" / "maxpool" / "upsample_argmax" */
-  char kernel[32];    /* kernel family: "conv_igemm", "head1x1", ... */
+  char kernel[32];    /* kernel family: "conv_dma", "head1x1", ... */
   float ms;           /* mean HIP-event time around the launch on the forward's stream */
   int32_t calls;      /* forwards averaged over */
   double flops;       /* algorithmic: 2*MAC of the convolution (0 for non-conv ops) */
@@ -186,12 +186,11 @@ int nbc_resize_cubic_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, floa
 int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_u8_dev, int32_t* row_lit_dev,
                       int out_h, int out_w, void* hip_stream);
 
-/* Tuning / test knob for the convolution kernel: impl 1 = LDS-DMA ring (default), 0 = the
- * register-staged reference kernel; tile = -1 (per-layer choice) or 0..12 = 128x64, 128x128,
+/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..12 = 128x64, 128x128,
  * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave
  * 128x128 and 128x64, the 16-wave 256x128 and (bf16) the 16-wave 256x256 (pixels x channels), forced wherever
  * the layer's Cout and the precision allow it. */
-int nbc_set_conv_impl(nbc_ctx* ctx, int impl, int tile);
+int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
 
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real
  * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the

@@ -71,7 +71,7 @@ SIGNATURES = {
     "nbc_set_plan_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     "nbc_default_conv_tile": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "nbc_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "nbc_set_conv_impl": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nbc_set_conv_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "nbc_set_keep_activations": (C.c_int, [C.c_void_p, C.c_int]),
     "nbc_read_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_int64 * 4)]),

@@ -1,7 +1,8 @@
-// Implicit-GEMM convolution, LDS-DMA pipeline ("v2"): the production conv kernel of the path.
+// Implicit-GEMM convolution, LDS-DMA pipeline: the conv kernel of the path.
 //
-// Same GEMM view, K-step (128 bytes of K per row), LDS image (XOR-swizzled 16-byte chunks) and
-// fused BN(+residual)(+ReLU) epilogue as conv_igemm.hip; what changes is how tiles reach LDS:
+// GEMM view D[n][m] = sum_k W[n][k] X[m][k] with m = output pixel (image, oy, ox), n = output channel,
+// k = (kh, kw, ci) walked in K-steps of 128 bytes per row; LDS image [rows][128 B] with XOR-swizzled
+// 16-byte chunks; fused BN(+residual)(+ReLU) epilogue.  How tiles reach LDS:
 //
 //   * LDS-DMA (buffer_load_dwordx4 ... lds through a buffer resource over the activation / weight
 //     buffer): each lane names a 16-byte SOURCE by a 32-bit offset (a pixel's channel chunk, a
@@ -20,7 +21,7 @@
 //   * tile shape is a template parameter chosen per layer on the host (enough tiles to fill 256
 //     CUs at batch 1, the largest tile otherwise: L2->LDS traffic per FLOP falls with tile size).
 //
-// D[n][m] orientation as in v1: weights are the MFMA A operand, pixels the B operand, so a lane
+// D[n][m] orientation: weights are the MFMA A operand, pixels the B operand, so a lane
 // ends up holding one pixel (column) and groups of four consecutive output channels (rows).
 #include <cstdlib>
 
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   NBC_STAMP(0);                                     // block start
 
-  // ---- tile coordinates (XCD-contiguous, n fastest; see conv_igemm.hip)
+  // ---- tile coordinates: blocks that share an XCD (blockIdx % 8) take a contiguous range of tiles, channel tiles
+  // fastest, so the channel tiles of a pixel tile and the halo rows of neighbouring pixel tiles meet in one L2
   const int tiles_n = p.Co / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
@@ -876,6 +878,8 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   }
   if (tile < 0) tile = choose_conv_tile(a.M, a.Co, a.ksteps * (128 / eb), precision);
   if (!conv_tile_ok(precision, tile, a.Co)) return hipErrorInvalidValue;
+#ifdef NBC_DIAG
+  // measurement builds only (tools/build_tools.sh): the library never reads these variables
   // NBC_CONV_ABLATE=1 (no MFMA) / 2 (no refill DMA): timing-only builds of the bf16 256x256 and
   // 128x256 tiles, results are garbage.  Never set outside an experiment.
   static const int ablate = [] { const char* e = getenv("NBC_CONV_ABLATE"); return e ? atoi(e) : 0; }();
@@ -889,15 +893,19 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
       default: return tile == 3 ? launch_cfg<1, 2, 4, 4, 2, 2, false, 7>(a, s) : launch_cfg<1, 2, 4, 2, 2, 3, false, 7>(a, s);
     }
   }
+#endif
   if (precision == 0) return a.stem ? launch_tile<0, true, 0>(a, tile, s) : launch_tile<0, false, 0>(a, tile, s);
   if (a.stem) return launch_tile<1, true, 0>(a, tile, s);
   // bf16: the MFMA-heavy layers run on v_mfma_f32_16x16x32_bf16 (VAR 0: +4-5 % measured on the
   // head and layer4 3x3 convs, the chip holds a higher clock on it); the residual 1x1 layers keep
   // v_mfma_f32_32x32x16_bf16 (VAR 1), whose fragment registers leave room for the identity prefetch
   // on the 256x256 tile.  The choice depends on the layer only, never on the tile, so the
-  // tile-invariance of the results holds.  NBC_CONV_MFMA32=1 forces VAR 1 everywhere (A/B runs).
-  static const int mfma32 = [] { const char* e = getenv("NBC_CONV_MFMA32"); return e ? atoi(e) : 0; }();
-  if (a.res != nullptr || mfma32) return launch_tile<1, false, 1>(a, tile, s);
+  // tile-invariance of the results holds.
+#ifdef NBC_DIAG
+  static const int mfma32 = [] { const char* e = getenv("NBC_CONV_MFMA32"); return e ? atoi(e) : 0; }();   // A/B runs
+  if (mfma32) return launch_tile<1, false, 1>(a, tile, s);
+#endif
+  if (a.res != nullptr) return launch_tile<1, false, 1>(a, tile, s);
   return launch_tile<1, false, 0>(a, tile, s);
 }
 

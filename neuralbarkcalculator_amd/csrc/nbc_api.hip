@@ -64,8 +64,7 @@ struct nbc_ctx {
   std::vector<size_t> buf_cap;
   float* lowres = nullptr;
   size_t lowres_cap = 0;
-  int conv_impl = 1;                        // 1 = LDS-DMA ring (v2), 0 = register-staged (v1)
-  int conv_tile = -1;                       // v2 tile override, -1 = per-layer choice
+  int conv_tile = -1;                       // tile override, -1 = per-layer choice
   bool keep = false;
   bool profiling = false;
   // profiling: one event set (nops+1 events) per profiled forward, read back lazily so that the
@@ -252,7 +251,7 @@ int ensure_buffers(nbc_ctx* c) {
 }
 
 // One convolution launch of the plan (shared by nbc_forward and nbc_autotune).
-int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream_t s, hipError_t* err) {
+int launch_conv_op(nbc_ctx* c, const Op& o, int N, int tile, hipStream_t s, hipError_t* err) {
   const auto& units = conv_units();
   const ConvUnit& u = units[o.unit];
   const PackedConv& pc = c->layout.convs[o.unit];
@@ -284,14 +283,14 @@ int launch_conv_op(nbc_ctx* c, const Op& o, int N, int impl, int tile, hipStream
     return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
   a.x_bytes = (unsigned)xb;
   a.w_bytes = (unsigned)wbts;
-  *err = impl == 0 ? launch_conv_igemm(a, prec, s) : launch_conv_dma(a, prec, tile, s);
+  *err = launch_conv_dma(a, prec, tile, s);
   return NBC_OK;
 }
 
 const char* kernel_name(OpKind k) {
   switch (k) {
     case OP_INGEST: return "ingest";
-    case OP_CONV: return "conv_igemm";
+    case OP_CONV: return "conv_dma";
     case OP_MAXPOOL: return "maxpool";
     case OP_HEAD1X1: return "head1x1";
     default: return "upsample_argmax";
@@ -428,11 +427,9 @@ int nbc_set_normalization(nbc_ctx* c, const float mean[3], const float stdv[3]) 
   return NBC_OK;
 }
 
-int nbc_set_conv_impl(nbc_ctx* c, int impl, int tile) {
+int nbc_set_conv_tile(nbc_ctx* c, int tile) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
-  if (impl != 0 && impl != 1) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: impl must be 0 or 1");
-  if (tile < -1 || tile >= CONV_TILE_COUNT) return set_error(NBC_ERR_INVALID, "nbc_set_conv_impl: bad tile id");
-  c->conv_impl = impl;
+  if (tile < -1 || tile >= CONV_TILE_COUNT) return set_error(NBC_ERR_INVALID, "nbc_set_conv_tile: bad tile id");
   c->conv_tile = tile;
   return NBC_OK;
 }
@@ -513,7 +510,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
       case OP_CONV: {
         int tile = c->conv_tile;
         if (!conv_tile_ok(prec, tile, o.Co)) tile = o.tile;   // no override, or it does not fit: planned tile
-        rc = launch_conv_op(c, o, N, c->conv_impl, tile, s, &e);
+        rc = launch_conv_op(c, o, N, tile, s, &e);
         if (rc != NBC_OK) return rc;
         break;
       }
@@ -600,10 +597,10 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
       if (!conv_tile_ok(c->precision, tile, o.Co)) continue;
       hipError_t e = hipSuccess;
-      rc = launch_conv_op(c, o, N, 1, tile, s, &e);                       // warm-up (and attribute set-up)
+      rc = launch_conv_op(c, o, N, tile, s, &e);                          // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
       (void)hipEventRecord(e0, s);
-      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, N, 1, tile, s, &e);
+      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, N, tile, s, &e);
       (void)hipEventRecord(e1, s);
       if (hipEventSynchronize(e1) != hipSuccess) continue;
       float ms = 0.f;

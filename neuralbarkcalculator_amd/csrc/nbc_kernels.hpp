@@ -1,4 +1,4 @@
-// Launchers of the gfx950 kernels (definitions in conv_igemm.hip and pointwise.hip).
+// Launchers of the gfx950 kernels (definitions in conv_igemm_dma.hip, pointwise.hip and small_zones.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -31,11 +31,8 @@ struct ConvArgs {
 #endif
 };
 
-// precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_32x32x16_bf16)
-// v1: register-staged, 128 x {64,128} tiles (conv_igemm.hip); kept as the A/B reference kernel.
-hipError_t launch_conv_igemm(const ConvArgs& a, int precision, hipStream_t s);
-
-// v2: LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
+// precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16)
+// LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
 constexpr int CONV_TILE_COUNT = 13;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);

@@ -586,12 +586,11 @@ hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int 
   const float scale_x = (float)w / (float)W;
   // the tiled kernel needs the block's tap window to fit its LDS image (always true for the
   // path's own x8 geometry: 36 x 5 taps); anything else takes the one-pixel-per-thread kernel
-  static const int up_rows = [] { const char* e = getenv("NBC_UP_ROWS"); const int v = e ? atoi(e) : 8; return v == 16 || v == 4 ? v : 8; }();
+  constexpr int up_rows = 8;                       // output rows per block (4 and 16 measured slower)
   const bool fits = (int)(scale_x * 255.0f) + 6 <= UP_WIN_C && (int)(scale_y * (up_rows - 1)) + 6 <= UP_WIN_R;
   if (fits) {
     dim3 grid((W + 255) / 256, (H + up_rows - 1) / up_rows, N);
-    auto kern = up_rows == 16 ? &upsample_argmax_tiled_kernel<16> : up_rows == 4 ? &upsample_argmax_tiled_kernel<4> : &upsample_argmax_tiled_kernel<8>;
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, lowres, h, w, H, W, scale_y,
+    hipLaunchKernelGGL(upsample_argmax_tiled_kernel<up_rows>, grid, dim3(256), 0, s, lowres, h, w, H, W, scale_y,
                        scale_x, logits_full, labels, labels_i64, counts, exclude_nodes);
   } else {
     dim3 grid((W + 255) / 256, H, N);

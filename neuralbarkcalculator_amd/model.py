@@ -298,11 +298,11 @@ class FCNResNet50:
                             k=int(rec.kh), cout=int(rec.cout)))
         return out
 
-    def set_conv_impl(self, impl: int = 1, tile: int = -1):
-        """Tuning/test knob: impl 1 = LDS-DMA ring kernel, 0 = register-staged kernel; tile -1 = auto,
+    def set_conv_tile(self, tile: int = -1):
+        """Tuning/test knob: tile -1 = per-layer choice,
         0..12 = 128x64 / 128x128 / 256x128 / 256x256 / 128x128 (4 stages) / 128x256 / 256x64 /
         128x64 (2 stages) / 64x128 / 128x128 (8 waves) / 128x64 (8 waves) / 256x128 (16 waves) / 256x256 (16 waves, bf16)."""
-        _lib.check(self._lib.nbc_set_conv_impl(self._require_ctx(), int(impl), int(tile)), "nbc_set_conv_impl")
+        _lib.check(self._lib.nbc_set_conv_tile(self._require_ctx(), int(tile)), "nbc_set_conv_tile")
 
     def autotune(self, x: torch.Tensor, reps: int = 3, objective: str = "latency"):
         """Measure every conv tile shape on every layer for x's (N,H,W) and keep the fastest per

@@ -34,15 +34,15 @@ for prec, batch, h in cases:
         torch.cuda.synchronize()
         r = m.op_records()
         m.set_profiling(False)
-        return [q for q in r if q["kernel"] == "conv_igemm"]
+        return [q for q in r if q["kernel"] == "conv_dma"]
 
     m.reserve(batch, h, 1024)
     default_tiles = m.plan_tiles()
     per_tile = {}
     for tile in range(N_TILES):
-        m.set_conv_impl(1, tile)            # forced wherever it fits the layer; elsewhere the planned tile runs
+        m.set_conv_tile(tile)            # forced wherever it fits the layer; elsewhere the planned tile runs
         per_tile[tile] = [q["ms"] for q in records()]
-    m.set_conv_impl(1, -1)
+    m.set_conv_tile(-1)
     base = records()
     tuned = m.autotune(x, reps=5)
     out["%s_b%d_h%d" % (prec, batch, h)] = dict(

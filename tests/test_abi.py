@@ -30,6 +30,15 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert b"gfx950" in built_lib.nbc_version()
 
 
+def test_library_holds_no_measurement_switches(built_lib):
+    """The timing-only variants of the conv kernel (no MFMA, no refill DMA, ...) and the A/B instruction switch
+    exist in the -DNBC_DIAG builds of tools/ only: the product library neither reads their environment variables
+    nor contains those kernel instantiations."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"NBC_CONV_ABLATE", b"NBC_CONV_MFMA32", b"getenv"):
+        assert needle not in blob, needle
+
+
 def test_topology_through_the_abi(built_lib):
     units = topology.conv_units()
     assert built_lib.nbc_num_convs() == len(units) == 55
