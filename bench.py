@@ -69,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--no-bf16-leg", action="store_true", help="skip the configs[2] object (batch 8, bf16)")
     ap.add_argument("--bf16-steps", type=int, default=0, help="steps of the configs[2] leg (default: max(10, K/5))")
     ap.add_argument("--bf16-streams", type=int, default=2)
+    ap.add_argument("--sub-batch", default="auto",
+                    help="sub-batched tail of a leg with batch > 1: 'auto' (the library's default), 'off', or "
+                         "'<first op>:<images>', e.g. backbone.layer4.0.conv1:2")
     ap.add_argument("--no-op-events", action="store_true", help="no instrumented region (no roofline object)")
     ap.add_argument("--save-tiles", default=None, help="write the measured per-layer tile choices (JSON) to this file")
     ap.add_argument("--tiles-file", default=None,
@@ -209,6 +212,13 @@ def main():
         for i in range(nf):
             b = np.stack([frames[(i + j) % nf] for j in range(batch)])
             batches.append(torch.from_numpy(b).to(dev))
+        def apply_sub_batch(m):
+            if args.sub_batch == "off":
+                m.set_sub_batch(None, 0)
+            elif args.sub_batch != "auto":
+                name, n = args.sub_batch.rsplit(":", 1)
+                m.set_sub_batch(name, int(n))
+        apply_sub_batch(model)
         model.reserve(batch, H, W)
         model.set_conv_tile(args.conv_tile)
         tiles = None
@@ -226,6 +236,7 @@ def main():
         models = [model]
         for _ in range(nstreams - 1):
             m2 = model.clone_shared()
+            apply_sub_batch(m2)
             m2.reserve(batch, H, W)
             m2.set_conv_tile(args.conv_tile)
             if tune:

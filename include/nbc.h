@@ -80,16 +80,17 @@ typedef struct {
   int32_t relu, bias, residual;
 } nbc_conv_desc;
 
-/* Per-launch record of the last profiled forward (nbc_set_profiling). */
+/* Per-op record of the last profiled forwards (nbc_set_profiling). */
 typedef struct {
   char name[64];      /* conv unit name, or "ingest" / "maxpool" / "upsample_argmax" */
   char kernel[32];    /* kernel family: "conv_dma", "head1x1", ... */
-  float ms;           /* mean HIP-event time around the launch on the forward's stream */
+  float ms;           /* mean HIP-event time of the op per forward on the forward's stream (all its launches together) */
   int32_t calls;      /* forwards averaged over */
   double flops;       /* algorithmic: 2*MAC of the convolution (0 for non-conv ops) */
   double bytes;       /* algorithmic: input read once + weights once + output once (+ identity) */
   int32_t kh, kw;     /* kernel extent (0 for non-conv) */
   int32_t cout;       /* output channels (conv ops): Co % 128 == 0 selects the wide-tile kernel */
+  int32_t launches;   /* launches of the op per forward: 1, or the number of sub-batches (nbc_set_sub_batch) */
 } nbc_op_record;
 
 const char* nbc_last_error(void);
@@ -191,6 +192,15 @@ int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_
  * 128x128 and 128x64, the 16-wave 256x128 and (bf16) the 16-wave 256x256 (pixels x channels), forced wherever
  * the layer's Cout and the precision allow it. */
 int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
+
+/* Sub-batched tail.  With N images per call the 2048-channel residual stream of layer4 is 67 MB per image in bf16
+ * (134 MB in f32): at N = 8 every 1x1 + identity launch streams 1.2 GB through HBM.  After this call the plan runs
+ * the ops in front of `first_op` once on the whole batch and everything from `first_op` to classifier.4 depth-first on
+ * `images` images at a time, in buffers sized for (and re-used by) one sub-batch, so that those tensors stay in the
+ * 256-MB Infinity Cache.  Same kernels, same K order: results are bit-identical to the whole-batch plan.
+ * `first_op` is the first convolution of a bottleneck ("backbone.layer3.0.conv1", ...) or "classifier.0";
+ * NULL or images < 1 turns it off (the default).  Calls with N <= images, and keep-activations mode, run whole-batch. */
+int nbc_set_sub_batch(nbc_ctx* ctx, const char* first_op, int images);
 
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real
  * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the

@@ -34,7 +34,7 @@ class NbcConvDesc(C.Structure):
 class NbcOpRecord(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("kernel", C.c_char * 32), ("ms", C.c_float), ("calls", C.c_int32),
                 ("flops", C.c_double), ("bytes", C.c_double), ("kh", C.c_int32), ("kw", C.c_int32),
-                ("cout", C.c_int32)]
+                ("cout", C.c_int32), ("launches", C.c_int32)]
 
 
 # every symbol include/nbc.h declares: (restype, argtypes)
@@ -55,6 +55,7 @@ SIGNATURES = {
     "nbc_load_weights": (C.c_int, [C.c_void_p, C.POINTER(NbcTensor), C.c_int, C.c_int]),
     "nbc_set_normalization": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "nbc_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "nbc_set_sub_batch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nbc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p]),

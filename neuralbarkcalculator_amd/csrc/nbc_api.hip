@@ -38,6 +38,7 @@ struct Op {
   std::string name;
   double flops, bytes;
   int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
+  bool in_full, res_full;   // sub-batched tail: the input / identity buffer holds the whole batch (the image offset applies)
 };
 
 struct Plan {
@@ -46,6 +47,12 @@ struct Plan {
   int h = 0, w = 0;                    // low-res logits size
   std::vector<Op> ops;
   std::vector<size_t> buf_bytes;       // per activation buffer
+  // Sub-batched tail (nbc_set_sub_batch): ops [0, sub_from) run once on all N images, ops [sub_from, upsample)
+  // run depth-first on sub_n images at a time in buffers sized (and re-used) for sub_n images, so that the
+  // wide residual stream of layer3 / layer4 stays in the 256-MB Infinity Cache; -1 = the whole plan on N images.
+  int sub_from = -1, sub_n = 0;
+  std::string sub_first;               // the request the plan was built for (part of its identity)
+  int sub_req = 0;
 };
 
 }  // namespace
@@ -65,6 +72,8 @@ struct nbc_ctx {
   float* lowres = nullptr;
   size_t lowres_cap = 0;
   int conv_tile = -1;                       // tile override, -1 = per-layer choice
+  std::string sub_first;                    // sub-batched tail: its first op ("" = none) ...
+  int sub_n = 0;                            // ... and images per sub-batch (nbc_set_sub_batch)
   bool keep = false;
   bool profiling = false;
   // profiling: one event set (nops+1 events) per profiled forward, read back lazily so that the
@@ -72,6 +81,7 @@ struct nbc_ctx {
   std::vector<std::vector<hipEvent_t>> prof_sets;
   size_t prof_used = 0;
   std::vector<Op> prof_ops;
+  std::vector<int> prof_launch_op;          // op index of each launch of a profiled forward (sub-batches repeat ops)
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
   void* scratch256 = nullptr;               // 256 bytes of device scratch (min/max of the preprocessor resize)
@@ -86,6 +96,9 @@ constexpr size_t kPlanCacheEntries = 64;
 bool same_shape(const Plan& p, int N, int H, int W, int precision, bool keep) {
   return p.N == N && p.H == H && p.W == W && p.precision == precision && p.keep == keep;
 }
+bool same_plan(const Plan& p, const nbc_ctx* c, int N, int H, int W) {
+  return same_shape(p, N, H, W, c->precision, c->keep) && p.sub_first == c->sub_first && p.sub_req == c->sub_n;
+}
 
 // Park the current plan (folders of height-trimmed images alternate between a few shapes: each keeps
 // its launch list and its measured tile choice instead of being rebuilt on every change).
@@ -93,7 +106,9 @@ void stash_plan(nbc_ctx* c) {
   Plan& cur = c->plan;
   if (cur.N == 0) return;
   for (Plan& p : c->plan_cache)
-    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep)) { p = cur; cur = Plan(); return; }
+    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep) && p.sub_first == cur.sub_first && p.sub_req == cur.sub_req) {
+      p = cur; cur = Plan(); return;
+    }
   if (c->plan_cache.size() >= kPlanCacheEntries) c->plan_cache.erase(c->plan_cache.begin());
   c->plan_cache.push_back(cur);
   cur = Plan();
@@ -104,6 +119,13 @@ void stash_plan(nbc_ctx* c) {
 int build_plan(nbc_ctx* c, int N, int H, int W) {
   Plan P;
   P.N = N; P.H = H; P.W = W; P.precision = c->precision; P.keep = c->keep;
+  P.sub_first = c->sub_first; P.sub_req = c->sub_n;
+  // the tail runs in sub-batches when one is asked for, it is smaller than the batch, and every op keeps its own
+  // buffer for the whole batch is not asked for (layer-by-layer tests read whole-batch activations)
+  const bool want_sub = !c->sub_first.empty() && c->sub_n >= 1 && c->sub_n < N && !c->keep;
+  bool in_tail = false;                // set when the op named sub_first is reached
+  int boundary = -1;                   // the whole-batch buffer the tail starts from: never recycled inside the tail
+  int NB = N;                          // images per launch of the ops being added
   const int eb = elem_bytes(c->precision);
   const auto& units = conv_units();
   const auto& L = c->layout;
@@ -117,7 +139,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     P.buf_bytes.push_back(bytes);
     return (int)in_use.size() - 1;
   };
-  auto release = [&](int b) { if (b >= 0 && !P.keep) in_use[b] = false; };
+  auto release = [&](int b) { if (b >= 0 && !P.keep && b != boundary) in_use[b] = false; };
 
   auto conv_out = [](int x, int k, int s, int p, int d) { return (x + 2 * p - d * (k - 1) - 1) / s + 1; };
 
@@ -136,11 +158,16 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     const ConvUnit& u = units[ui];
     const int Ho = conv_out(inH, u.k, u.stride, u.pad, u.dil);
     const int Wo = conv_out(inW, u.k, u.stride, u.pad, u.dil);
+    if (want_sub && !in_tail && c->sub_first == u.name) {   // the tail starts here, from the buffer this op reads
+      in_tail = true; boundary = in_buf; NB = c->sub_n;
+      P.sub_from = (int)P.ops.size(); P.sub_n = NB;
+    }
     Op o{};
     o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
+    o.in_full = in_tail && in_buf == boundary; o.res_full = in_tail && res_buf >= 0 && res_buf == boundary;
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
-    o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
-    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision);
+    o.out_buf = acquire((size_t)NB * Ho * Wo * u.cout * eb);
+    o.tile = choose_conv_tile(NB * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
     o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +
@@ -250,18 +277,21 @@ int ensure_buffers(nbc_ctx* c) {
   return NBC_OK;
 }
 
-// One convolution launch of the plan (shared by nbc_forward and nbc_autotune).
-int launch_conv_op(nbc_ctx* c, const Op& o, int N, int tile, hipStream_t s, hipError_t* err) {
+// One convolution launch of the plan (shared by nbc_forward and nbc_autotune): N images, the first of which is
+// image img0 of the whole-batch buffers (sub-batched tail; 0 otherwise).
+int launch_conv_op(nbc_ctx* c, const Op& o, int N, int img0, int tile, hipStream_t s, hipError_t* err) {
   const auto& units = conv_units();
   const ConvUnit& u = units[o.unit];
   const PackedConv& pc = c->layout.convs[o.unit];
   const int prec = c->precision;
+  const size_t eb = elem_bytes(prec);
   ConvArgs a{};
-  a.x = c->bufs[o.in_buf];
+  a.x = static_cast<const unsigned char*>(c->bufs[o.in_buf]) + (o.in_full ? (size_t)img0 * o.Hi * o.Wi * o.Ci * eb : 0);
   a.w = c->weights + pc.w_off;
   a.scale = reinterpret_cast<const float*>(c->weights + pc.scale_off);
   a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
-  a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
+  a.res = o.res_buf >= 0 ? static_cast<const unsigned char*>(c->bufs[o.res_buf]) + (o.res_full ? (size_t)img0 * o.Ho * o.Wo * o.Co * eb : 0)
+                          : nullptr;
   a.y = c->bufs[o.out_buf];
   a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
   a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
@@ -277,7 +307,7 @@ int launch_conv_op(nbc_ctx* c, const Op& o, int N, int tile, hipStream_t s, hipE
     if ((1 << sft) == o.Ho * o.Wo) a.hw_shift = sft;
   }
   if (o.Ci != pc.cin_pad) return set_error(NBC_ERR_STATE, "plan/channel mismatch at " + o.name);
-  const size_t xb = (size_t)N * o.Hi * o.Wi * o.Ci * elem_bytes(prec);
+  const size_t xb = (size_t)N * o.Hi * o.Wi * o.Ci * eb;
   const size_t wbts = (size_t)o.Co * pc.ksteps * kKStepBytes;
   if (xb >= 0x80000000ull || wbts >= 0x80000000ull)
     return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
@@ -441,6 +471,20 @@ int nbc_set_keep_activations(nbc_ctx* c, int on) {
   return NBC_OK;
 }
 
+int nbc_set_sub_batch(nbc_ctx* c, const char* first_op, int images) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  std::string name = first_op && images >= 1 ? first_op : "";
+  if (!name.empty()) {
+    bool ok = false;
+    for (const ConvUnit& u : conv_units())
+      if (name == u.name && (u.block_first || name == "classifier.0")) ok = true;
+    if (!ok) return set_error(NBC_ERR_INVALID, "nbc_set_sub_batch: '" + name + "' is not the first convolution of a bottleneck, nor classifier.0");
+  }
+  c->sub_first = name;
+  c->sub_n = name.empty() ? 0 : images;
+  return NBC_OK;                                     // the next nbc_forward / nbc_reserve plans accordingly
+}
+
 int nbc_set_profiling(nbc_ctx* c, int on) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
   c->profiling = on != 0;
@@ -452,11 +496,11 @@ int nbc_reserve(nbc_ctx* c, int N, int H, int W) {
   if (c->precision < 0) return set_error(NBC_ERR_STATE, "nbc_reserve: no weights attached");
   if (N < 1 || H < 8 || W < 8) return set_error(NBC_ERR_INVALID, "nbc_reserve: need N>=1, H>=8, W>=8");
   NBC_HIP(hipSetDevice(c->device));
-  if (same_shape(c->plan, N, H, W, c->precision, c->keep)) return NBC_OK;
+  if (same_plan(c->plan, c, N, H, W)) return NBC_OK;
   stash_plan(c);
   bool found = false;
   for (const Plan& p : c->plan_cache)
-    if (same_shape(p, N, H, W, c->precision, c->keep)) { c->plan = p; found = true; break; }
+    if (same_plan(p, c, N, H, W)) { c->plan = p; found = true; break; }
   if (!found) {
     int rc = build_plan(c, N, H, W);
     if (rc != NBC_OK) return rc;
@@ -480,24 +524,44 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
   const int prec = c->precision;
 
   const size_t nops = P.ops.size();
+  // launch list: (op, first image, images).  Without a sub-batched tail every op runs once on the whole batch;
+  // with one, ops [sub_from, upsample) run depth-first on sub_n images at a time.
+  struct Launch { int op, img0, nb; };
+  std::vector<Launch> launches;
+  launches.reserve(nops);
+  {
+    const int tail0 = P.sub_from >= 0 ? P.sub_from : (int)nops;
+    int tail1 = (int)nops;
+    for (size_t i = 0; i < nops; ++i)
+      if (P.ops[i].kind == OP_UPSAMPLE) tail1 = (int)i;
+    for (int i = 0; i < tail0; ++i) launches.push_back({i, 0, N});
+    if (P.sub_from >= 0)
+      for (int img0 = 0; img0 < N; img0 += P.sub_n)
+        for (int i = tail0; i < tail1; ++i) launches.push_back({i, img0, std::min(P.sub_n, N - img0)});
+    for (int i = P.sub_from >= 0 ? tail1 : tail0; i < (int)nops; ++i) launches.push_back({i, 0, N});
+  }
+  const size_t nl = launches.size();
   constexpr size_t kMaxProfSets = 4096;
   std::vector<hipEvent_t>* evs = nullptr;
   if (c->profiling && c->prof_used < kMaxProfSets) {
-    if (c->prof_used > 0 && c->prof_ops.size() != nops) c->prof_used = 0;   // plan changed: restart
+    if (c->prof_used > 0 && (c->prof_ops.size() != nops || c->prof_launch_op.size() != nl)) c->prof_used = 0;   // plan changed: restart
     if (c->prof_sets.size() <= c->prof_used) c->prof_sets.emplace_back();
     evs = &c->prof_sets[c->prof_used];
-    while (evs->size() < nops + 1) {
+    while (evs->size() < nl + 1) {
       hipEvent_t ev;
       NBC_HIP(hipEventCreate(&ev));
       evs->push_back(ev);
     }
     c->prof_ops = P.ops;
+    c->prof_launch_op.resize(nl);
+    for (size_t l = 0; l < nl; ++l) c->prof_launch_op[l] = launches[l].op;
   }
   float* lowres = logits_lowres_dev ? logits_lowres_dev : c->lowres;
 
   if (evs) NBC_HIP(hipEventRecord((*evs)[0], s));
-  for (size_t i = 0; i < nops; ++i) {
-    const Op& o = P.ops[i];
+  for (size_t l = 0; l < nl; ++l) {
+    const Op& o = P.ops[launches[l].op];
+    const int img0 = launches[l].img0, nb = launches[l].nb;
     hipError_t e = hipSuccess;
     int rc = NBC_OK;
     switch (o.kind) {
@@ -510,7 +574,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
       case OP_CONV: {
         int tile = c->conv_tile;
         if (!conv_tile_ok(prec, tile, o.Co)) tile = o.tile;   // no override, or it does not fit: planned tile
-        rc = launch_conv_op(c, o, N, tile, s, &e);
+        rc = launch_conv_op(c, o, nb, img0, tile, s, &e);
         if (rc != NBC_OK) return rc;
         break;
       }
@@ -520,9 +584,11 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
       case OP_HEAD1X1: {
         const PackedConv& pc = c->layout.convs[o.unit];
         if (o.Ci != 512) return set_error(NBC_ERR_STATE, "classifier.4 expects 512 input channels");
+        // also clears this launch's share of the counters (3 per image) when the batch has at most 256 of them
+        unsigned long long* cz = counts_dev && 3 * N <= 256 ? reinterpret_cast<unsigned long long*>(counts_dev) + 3 * img0 : nullptr;
         e = launch_head1x1(c->bufs[o.in_buf], reinterpret_cast<const float*>(c->weights + pc.w_off),
-                           reinterpret_cast<const float*>(c->weights + pc.shift_off), lowres, N, o.Ho * o.Wo, prec,
-                           reinterpret_cast<unsigned long long*>(counts_dev), s);   // also clears the counters
+                           reinterpret_cast<const float*>(c->weights + pc.shift_off),
+                           lowres + (size_t)img0 * kNumClasses * o.Ho * o.Wo, nb, o.Ho * o.Wo, prec, cz, s);
         break;
       }
       case OP_UPSAMPLE:
@@ -538,7 +604,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
     }
     if (e != hipSuccess)
       return set_error(NBC_ERR_HIP, "launch of " + o.name + " failed: " + hipGetErrorString(e));
-    if (evs) NBC_HIP(hipEventRecord((*evs)[i + 1], s));
+    if (evs) NBC_HIP(hipEventRecord((*evs)[l + 1], s));
   }
   if (evs) ++c->prof_used;
   return NBC_OK;
@@ -551,21 +617,28 @@ static int collect_profile(nbc_ctx* c) {
   if (c->prof_used == 0) return NBC_OK;
   const auto& units = conv_units();
   const size_t nops = c->prof_ops.size();
-  NBC_HIP(hipEventSynchronize(c->prof_sets[c->prof_used - 1][nops]));
+  const size_t nl = c->prof_launch_op.size();
+  NBC_HIP(hipEventSynchronize(c->prof_sets[c->prof_used - 1][nl]));
   c->records.assign(nops, nbc_op_record{});
+  std::vector<double> sum(nops, 0.0);
+  std::vector<int> per_forward(nops, 0);
+  for (size_t l = 0; l < nl; ++l) {
+    const int i = c->prof_launch_op[l];
+    ++per_forward[i];
+    for (size_t k = 0; k < c->prof_used; ++k) {
+      float ms = 0.f;
+      NBC_HIP(hipEventElapsedTime(&ms, c->prof_sets[k][l], c->prof_sets[k][l + 1]));
+      sum[i] += ms;
+    }
+  }
   for (size_t i = 0; i < nops; ++i) {
     const Op& o = c->prof_ops[i];
     nbc_op_record& r = c->records[i];
     std::snprintf(r.name, sizeof(r.name), "%s", o.name.c_str());
     std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel_name(o.kind));
-    double sum = 0.0;
-    for (size_t k = 0; k < c->prof_used; ++k) {
-      float ms = 0.f;
-      NBC_HIP(hipEventElapsedTime(&ms, c->prof_sets[k][i], c->prof_sets[k][i + 1]));
-      sum += ms;
-    }
-    r.ms = (float)(sum / (double)c->prof_used);
+    r.ms = (float)(sum[i] / (double)c->prof_used);     // per forward: all sub-batch launches of the op together
     r.calls = (int32_t)c->prof_used;
+    r.launches = per_forward[i];
     r.flops = o.flops;
     r.bytes = o.bytes;
     r.kh = r.kw = (o.kind == OP_CONV || o.kind == OP_HEAD1X1) ? units[o.unit].k : 0;
@@ -590,17 +663,19 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
   NBC_HIP(hipEventCreate(&e0));
   NBC_HIP(hipEventCreate(&e1));
   Plan& P = c->plan;
-  for (Op& o : P.ops) {
+  for (size_t oi = 0; oi < P.ops.size(); ++oi) {
+    Op& o = P.ops[oi];
     if (o.kind != OP_CONV) continue;
+    const int NB = P.sub_from >= 0 && (int)oi >= P.sub_from ? P.sub_n : N;   // images per launch of this op
     float best_ms = 1e30f;
     int best = o.tile;
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
       if (!conv_tile_ok(c->precision, tile, o.Co)) continue;
       hipError_t e = hipSuccess;
-      rc = launch_conv_op(c, o, N, tile, s, &e);                          // warm-up (and attribute set-up)
+      rc = launch_conv_op(c, o, NB, 0, tile, s, &e);                      // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
       (void)hipEventRecord(e0, s);
-      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, N, tile, s, &e);
+      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, NB, 0, tile, s, &e);
       (void)hipEventRecord(e1, s);
       if (hipEventSynchronize(e1) != hipSuccess) continue;
       float ms = 0.f;
@@ -608,7 +683,7 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
       if (objective == 1) {
         // throughput objective: several forwards run concurrently on other streams, so a launch that
         // fills only part of the chip costs only that part: weigh the time by the fraction of CUs used
-        const int tiles = ((N * o.Ho * o.Wo + conv_tile_rows(tile) - 1) / conv_tile_rows(tile)) * (o.Co / conv_tile_cols(tile));
+        const int tiles = ((NB * o.Ho * o.Wo + conv_tile_rows(tile) - 1) / conv_tile_rows(tile)) * (o.Co / conv_tile_cols(tile));
         if (tiles < 256) ms *= (float)tiles / 256.0f;
       }
       if (ms < best_ms) { best_ms = ms; best = tile; }

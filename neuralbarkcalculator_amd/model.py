@@ -295,8 +295,14 @@ class FCNResNet50:
             _lib.check(self._lib.nbc_get_op_record(self._ctx, i, C.byref(rec)))
             out.append(dict(name=rec.name.decode(), kernel=rec.kernel.decode(), ms=float(rec.ms),
                             calls=int(rec.calls), flops=float(rec.flops), bytes=float(rec.bytes),
-                            k=int(rec.kh), cout=int(rec.cout)))
+                            k=int(rec.kh), cout=int(rec.cout), launches=int(rec.launches)))
         return out
+
+    def set_sub_batch(self, first_op=None, images: int = 0):
+        """Run everything from conv unit `first_op` (the first convolution of a bottleneck, or "classifier.0") to
+        classifier.4 depth-first on `images` images at a time (nbc_set_sub_batch); None / 0 = whole-batch plan."""
+        name = first_op.encode() if first_op and images >= 1 else None
+        _lib.check(self._lib.nbc_set_sub_batch(self._require_ctx(), name, int(images)), "nbc_set_sub_batch")
 
     def set_conv_tile(self, tile: int = -1):
         """Tuning/test knob: tile -1 = per-layer choice,

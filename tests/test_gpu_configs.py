@@ -99,6 +99,50 @@ def test_batch8_equals_eight_singles_at_1024(gpu_fp32, gpu_bf16, mode):
         assert torch.equal(l1[0], labels[b]) and torch.equal(c1[0], counts[b]), f"frame {b} ({mode})"
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("first_op,images", [("backbone.layer3.0.conv1", 1), ("backbone.layer3.0.conv1", 2),
+                                             ("backbone.layer4.0.conv1", 2), ("backbone.layer4.1.conv1", 3),
+                                             ("backbone.layer1.0.conv1", 2), ("classifier.0", 1)])
+def test_sub_batched_tail_changes_nothing(gpu_fp32, gpu_bf16, mode, first_op, images):
+    """nbc_set_sub_batch: the tail of the plan run depth-first on `images` images at a time (with a ragged last
+    sub-batch where 5 is not a multiple) gives the whole-batch plan's labels, counts and low-res logits bit for bit;
+    so does the measured tile choice for the sub-batched plan."""
+    model = gpu_fp32 if mode == "fp32" else gpu_bf16
+    x = frames(range(70, 75), 192, 256).to(DEV)
+    ref = model.predict_labels(x, labels_dtype=torch.uint8, return_lowres=True)
+    torch.cuda.synchronize()
+    try:
+        model.set_sub_batch(first_op, images)
+        got = model.predict_labels(x, labels_dtype=torch.uint8, return_lowres=True)
+        torch.cuda.synchronize()
+        for a, b, what in zip(ref, got, ("labels", "counts", "low-res logits")):
+            assert torch.equal(a, b), f"{what} differ with the tail from {first_op} in sub-batches of {images} ({mode})"
+        launches = {r["name"]: r["launches"] for r in _profiled(model, x)}
+        assert launches["backbone.conv1"] == 1 and launches["upsample_argmax"] == 1
+        assert launches["classifier.0"] == -(-5 // images) and launches["classifier.4"] == -(-5 // images)
+        if first_op.startswith("backbone.layer4"):
+            assert launches["backbone.layer3.5.conv3"] == 1 and launches["backbone.layer4.2.conv3"] == -(-5 // images)
+        model.autotune(x)
+        got = model.predict_labels(x, labels_dtype=torch.uint8, return_lowres=True)
+        for a, b, what in zip(ref, got, ("labels", "counts", "low-res logits")):
+            assert torch.equal(a, b), f"{what} differ after autotune of the sub-batched plan ({mode})"
+        with pytest.raises(RuntimeError):
+            model.set_sub_batch("backbone.layer3.0.conv2", 2)       # not the first convolution of a bottleneck
+    finally:
+        model.set_sub_batch(None, 0)
+    again = model.predict_labels(x, labels_dtype=torch.uint8, return_lowres=True)
+    for a, b in zip(ref, again):
+        assert torch.equal(a, b)
+
+
+def _profiled(model, x):
+    model.set_profiling(True)
+    model.predict_labels(x, labels_dtype=torch.uint8)
+    recs = model.op_records()
+    model.set_profiling(False)
+    return recs
+
+
 @pytest.mark.parametrize("name", ["c128", "b2_256", "full1024"])
 def test_fp32_label_flips_adjudicated_by_float64(oracle_model, oracle_f64, gpu_fp32, name):
     from oracle.fcn_resnet50_oracle import predict_labels

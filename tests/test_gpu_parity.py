@@ -559,3 +559,24 @@ def test_bcast_weights_at_the_c_abi(built_lib, sd_np):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_bcast_weights_non_root_branch_with_a_stub(built_lib, tmp_path):
+    """The RECEIVING branch of nbc_bcast_weights (allocate, receive, attach, free the previous blob; a failed
+    collective leaves the context as it was), which a one-GPU box cannot reach with a real communicator: a child
+    process loads tests/helpers/rccl_stub.c (ncclCommUserRank says "rank 1", ncclBroadcast copies the planted root
+    blob device to device on the caller's stream) ahead of any RCCL and asserts that forwards on the received blob
+    equal the root's bit for bit, in both precisions.  A child, because the stub must be the first ncclBroadcast in
+    the global symbol scope and test_bcast_weights_at_the_c_abi puts the real one there."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = str(tmp_path / "librccl_stub.so")
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    os.path.join(here, "helpers", "rccl_stub.c"), "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", so], check=True)
+    r = subprocess.run([sys.executable, os.path.join(here, "helpers", "bcast_stub_driver.py"), so],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "bcast stub driver OK" in r.stdout
