@@ -40,10 +40,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md; f16x2 spends three f16 MFMAs per f32 product: its peak in f32-equivalent
+# (algorithmic) FLOPs is a third of the f16 peak
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f16x2": 2500.0 / 3.0}
 HBM_MEASURED = 6.29e12                          # achievable HBM bytes/s, same guide
 H = W = 1024
-DTYPE_NAME = {"fp32": "f32", "bf16": "bf16"}
+DTYPE_NAME = {"fp32": "f32", "bf16": "bf16", "f16x2": "f16x2"}
 
 
 def parse(argv=None):
@@ -51,7 +53,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="fp32",
+    ap.add_argument("--precision", choices=["bf16", "fp32", "f16x2"], default="fp32",
                     help="arithmetic of the HEADLINE run (fp32 = the reference's; bf16 only for A/B experiments)")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--streams", type=int, default=4,

@@ -48,7 +48,14 @@ enum {
 /* Arithmetic of the convolution stack. */
 enum {
   NBC_PREC_FP32 = 0,  /* f32 activations/weights, v_mfma_f32_32x32x2_f32: the parity mode */
-  NBC_PREC_BF16 = 1   /* bf16 activations/weights, f32 accumulate + f32 BN epilogue: throughput mode */
+  NBC_PREC_BF16 = 1,  /* bf16 activations/weights, f32 accumulate + f32 BN epilogue: throughput mode */
+  NBC_PREC_F16X2 = 2  /* f32-grade on the 16-bit matrix pipe: every f32 value x is kept as two f16 pieces, h0 = f16(x) and
+                         h1 = f16((x - h0) * 2^11) (x = h0 + h1 * 2^-11 to 2^-24 relative: one f32 rounding), 4 bytes per
+                         element like f32; a product is h0*h0' + (h0*h1' + h1*h0') * 2^-11, three EXACT f16 products on
+                         v_mfma_f32_16x16x32_f16 summed in f32 in two levels like the f32 mode (the dropped h1*h1' is 2^-24
+                         relative).  Error against float64 at the level of NBC_PREC_FP32 (profiles/r03_split_probe_*.log),
+                         same tolerances in the tests.  Values beyond +-65504 (f16's range) turn into NaN, never into a
+                         silently wrong number; activations of a batch-normalised network are orders of magnitude below. */
 };
 
 /* Layout of the image handed to nbc_forward. */
@@ -105,6 +112,12 @@ int nbc_state_key(int index, const char** name, int64_t shape[4], int32_t* ndim,
 int nbc_lowres_size(int H, int W, int* h, int* w);
 
 /* ---- weights (host side; no GPU needed) ------------------------------------------------ */
+/* The two f16 pieces NBC_PREC_F16X2 keeps of each of n f32 values (host arithmetic, bit patterns of IEEE binary16):
+ * h0 = f16(x) rounded to nearest even, h1 = f16((x - h0) * 2^11).  What nbc_pack_weights does to the weights in that
+ * mode and what the kernels do to every activation; exported so that the conversion can be checked against another
+ * implementation of binary16 rounding. */
+int nbc_split_f16x2(const float* x, size_t n, uint16_t* h0, uint16_t* h1);
+
 /* Size in bytes of the packed weight blob for a precision (same on every rank). */
 size_t nbc_packed_weights_bytes(int precision);
 /* Strict key/shape check like nn.Module.load_state_dict (models.py:222): NBC_ERR_KEYS with a

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libnbc_hip.so")
 
 NBC_OK = 0
 NBC_ERR_INVALID, NBC_ERR_KEYS, NBC_ERR_HIP, NBC_ERR_STATE, NBC_ERR_NOMEM = -1, -2, -3, -4, -5
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_F16X2 = 0, 1, 2
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
 LABEL_U8, LABEL_I64 = 0, 1
 
@@ -48,6 +48,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "nbc_lowres_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nbc_packed_weights_bytes": (C.c_size_t, [C.c_int]),
+    "nbc_split_f16x2": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "nbc_pack_weights": (C.c_int, [C.POINTER(NbcTensor), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "nbc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nbc_destroy": (C.c_int, [C.c_void_p]),

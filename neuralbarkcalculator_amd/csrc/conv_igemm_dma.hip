@@ -28,6 +28,7 @@
 #include <atomic>
 
 #include "nbc_kernels.hpp"
+#include "split16.hpp"
 
 namespace nbc {
 namespace {
@@ -119,7 +120,8 @@ constexpr int min_waves_per_simd(int prec, int wm, int wn, int mt, int nt, int s
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
 __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, NT, S)) void conv_dma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int EB = PREC == 0 ? 4 : 2;
+  constexpr int EB = PREC == 1 ? 2 : 4;           // f16x2: two f16 pieces per element, the f32 mode's geometry
+  constexpr bool X2 = (PREC == 2);
   constexpr int THREADS = WM * WN * 64;
   constexpr int BM = WM * MT * 32;
   constexpr int BN = WN * NT * 32;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   // bf16 uses v_mfma_f32_16x16x32_bf16 (VAR 0): same cycles per FLOP as 32x32x16 but the chip holds a
   // higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7); VAR 1 keeps the
   // 32x32x16 form for A/B runs.  f32 always uses 32x32x2.
-  constexpr bool M16 = (PREC == 1 && (VAR == 0 || VAR == 4));
+  constexpr bool M16 = (PREC == 1 && (VAR == 0 || VAR == 4)) || X2;
   constexpr int MT16 = 2 * MT, NT16 = 2 * NT;
   const int r16 = lane & 15, q16 = lane >> 4;
   // f32 (parity mode) sums in two levels: the 32 products of a K-step go through the MFMA's own fma chain
@@ -286,6 +288,19 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   f32x16 acc[M16 ? 1 : NT][M16 ? 1 : MT];
   f32x16 accI[F32 ? NT : 1][F32 ? MT : 1];
   f32x4 acc16[M16 ? NT16 : 1][M16 ? MT16 : 1];
+  // f16x2 (NBC_PREC_F16X2, split16.hpp): a K-step is 32 channels, its LDS row [h0 x 32][h1 x 32].  Per 16x16 tile and
+  // K-step three v_mfma_f32_16x16x32_f16: W0.X0 into accI2 (a chain of FLUSH K-steps = 256 exact products, then added
+  // to acc16 and cleared: the f32 mode's two-level sum), W1.X0 and W0.X1 into accS2, which carries 2^11 and joins at
+  // the end (its own rounding errors weigh 2^-11).  The dropped W1.X1 is 2^-24 relative.
+  f32x4 accI2[X2 ? NT16 : 1][X2 ? MT16 : 1], accS2[X2 ? NT16 : 1][X2 ? MT16 : 1];
+  if constexpr (X2) {
+#pragma unroll
+    for (int j = 0; j < NT16; ++j)
+#pragma unroll
+      for (int i = 0; i < MT16; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { accI2[j][i][e] = 0.f; accS2[j][i][e] = 0.f; }
+  }
   if constexpr (M16) {
 #pragma unroll
     for (int j = 0; j < NT16; ++j)
@@ -404,9 +419,71 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
 
   // Fragments are double-buffered in registers: the ds_read_b128 of chunk pair ks+1 are issued
   // before the MFMAs of chunk pair ks, so LDS latency hides under the matrix pipe.
-  auto compute = [&](int stage, bool do_issue, int t_issue, int issue_stage) {
+  auto compute = [&](int t, int stage, bool do_issue, int t_issue, int issue_stage) {
     const unsigned char* sa = smem + stage * STAGE_BYTES;
     const unsigned char* sb = sa + A_BYTES;
+    if constexpr (X2) {
+      constexpr int NTI = NT16 * MT16;
+      if (t > 0 && (t & 7) == 0) {                     // wave-uniform: the chain of the last eight K-steps joins the sum
+#pragma unroll
+        for (int n = 0; n < NTI; ++n) {
+          acc16[n / MT16][n % MT16] += accI2[n / MT16][n % MT16];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accI2[n / MT16][n % MT16][e] = 0.f;
+        }
+      }
+      if constexpr (!STEM) {
+        // lane (r16, q16) reads, of row r16 of every 16-row block, chunk q16 (h0 of channels 8*q16..) and chunk 4 + q16 (h1)
+        uint4 p0[MT16], p1[MT16], w0[NT16], w1[NT16];
+#pragma unroll
+        for (int i = 0; i < MT16; ++i) {
+          p0[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, q16));
+          p1[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, 4 + q16));
+        }
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) {
+          w0[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, q16));
+          w1[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, 4 + q16));
+        }
+        // product-major: two MFMAs on one accumulator are NTI instructions apart
+#pragma unroll
+        for (int idx = 0; idx < 3 * NTI; ++idx) {
+          const int prod = idx / NTI, n = idx % NTI, j = n / MT16, i = n % MT16;
+          if (prod == 0)
+            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p0[i]), accI2[j][i], 0, 0, 0);
+          else if (prod == 1)
+            accS2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1[j]), __builtin_bit_cast(f16x8, p0[i]), accS2[j][i], 0, 0, 0);
+          else
+            accS2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p1[i]), accS2[j][i], 0, 0, 0);
+          if (do_issue && (idx + 1) % (3 * NTI / 4) == 0) issue_part((idx + 1) / (3 * NTI / 4) - 1, t_issue, issue_stage);   // wave-uniform
+        }
+      } else {
+        // stem: a chunk is one tap, [h0 x 4][h1 x 4] (3 channels + a zero).  With the weight chunk as (w0, 0) the MFMA
+        // sums w0.x0, with its halves swapped, (w1, w0), it sums w1.x0 + w0.x1: two MFMAs per tile and half
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint4 px[MT16], wz[NT16], ws[NT16];
+#pragma unroll
+          for (int i = 0; i < MT16; ++i) px[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, 4 * half + q16));
+#pragma unroll
+          for (int j = 0; j < NT16; ++j) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, 4 * half + q16));
+            wz[j] = make_uint4(wv.x, wv.y, 0u, 0u);
+            ws[j] = make_uint4(wv.z, wv.w, wv.x, wv.y);
+          }
+#pragma unroll
+          for (int idx = 0; idx < 2 * NTI; ++idx) {
+            const int prod = idx / NTI, n = idx % NTI, j = n / MT16, i = n % MT16;
+            if (prod == 0)
+              accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wz[j]), __builtin_bit_cast(f16x8, px[i]), accI2[j][i], 0, 0, 0);
+            else
+              accS2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ws[j]), __builtin_bit_cast(f16x8, px[i]), accS2[j][i], 0, 0, 0);
+            if (do_issue && (idx + 1) % NTI == 0) issue_part(2 * half + (idx + 1) / NTI - 1, t_issue, issue_stage);
+          }
+        }
+      }
+      return;
+    }
     if constexpr (VAR == 6) {                        // timing-only ablation: DMA + barriers only
       if (do_issue) {
 #pragma unroll
@@ -493,13 +570,13 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   // ---- epilogue geometry (needed before the last K-step: the identity tile is prefetched there)
   constexpr int SLAB_CH = NT * 32;                  // channels of the wave's slab
   constexpr int PITCH = SLAB_CH * 4 + 16;           // f32 scratch row, padded against bank conflicts
-  constexpr int OUT_CH = 16 / EB;                   // channels per 16 output bytes
+  constexpr int OUT_CH = X2 ? 8 : 16 / EB;          // channels per lane and pass: 16 output bytes (f16x2: an h0 chunk and an h1 chunk)
   constexpr int CPR = SLAB_CH / OUT_CH;             // 16-byte output chunks per pixel row
   constexpr int PIX_PER_PASS = 64 / CPR;
   constexpr int PASSES = 32 / PIX_PER_PASS;
   // identity prefetch: <= 64 VGPRs per lane, and not on the 128x64 wave tile of the 16x16 path
   // (128 accumulators + 48 fragment registers leave no room: it spilled)
-  constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && (VAR == 0 || VAR == 4) && MT * NT >= 8);
+  constexpr bool RES_PREFETCH = (MT * PASSES <= 16) && !(PREC == 1 && (VAR == 0 || VAR == 4) && MT * NT >= 8) && !X2;
   static_assert(WM * WN * 32 * PITCH <= TABLE_OFF, "epilogue scratch must fit below the scale/shift table");
   // Output addressing: a wave-uniform 64-bit base (first pixel of the tile, first channel of the wave's
   // slab) plus a 32-bit per-lane offset (row inside the tile x row pitch + the lane's 16-byte chunk).
@@ -511,7 +588,8 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
   const unsigned char* rtile = p.res ? static_cast<const unsigned char*>(p.res) + tile_off : nullptr;
   const int rows_valid = p.M - m0;                  // rows of this tile inside the image batch (>= 1)
   const int row0 = wm * MT * 32 + o_pix;            // + i*32 + pass*PIX_PER_PASS
-  const unsigned lane_chunk = (unsigned)o_chunk * 16u;
+  // byte offset of the lane's chunk behind the slab's first channel (f16x2: the h0 chunk; its h1 chunk is 64 bytes on)
+  const unsigned lane_chunk = X2 ? (unsigned)(o_chunk >> 2) * 128u + (unsigned)(o_chunk & 3) * 16u : (unsigned)o_chunk * 16u;
   uint4 rpre[RES_PREFETCH ? MT : 1][RES_PREFETCH ? PASSES : 1];
 
   const int T = p.ksteps;
@@ -583,9 +661,9 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
     if constexpr (S == 2) {
       if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
       if constexpr (F32) step32(t, t % S, false, false, 0, false, 0, 0);
-      else compute(t % S, false, 0, 0);
+      else compute(t, t % S, false, 0, 0);
     } else {
-      compute(t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
+      compute(t, t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
     }
   }
   // last K-step, peeled: every DMA has retired, so the identity (residual) tile of the epilogue is
@@ -599,12 +677,21 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
 #endif
   prefetch_identity();
   if constexpr (F32) step32(T - 1, (T - 1) % S, false, false, 0, false, 0, 0);
-  else compute((T - 1) % S, false, 0, 0);
+  else compute(T - 1, (T - 1) % S, false, 0, 0);
   }
 
   if constexpr (F32) {                                // the last chain joins the running sum
 #pragma unroll
     for (int n = 0; n < NTILES; ++n) acc[n / MT][n % MT] += accI[n / MT][n % MT];
+  }
+  if constexpr (X2) {                                 // likewise, then the cross terms (they carry 2^11)
+#pragma unroll
+    for (int n = 0; n < NT16 * MT16; ++n) {
+      const int j = n / MT16, i = n % MT16;
+      const f32x4 big = acc16[j][i] + accI2[j][i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc16[j][i][e] = __builtin_fmaf(accS2[j][i][e], kH1Unscale, big[e]);
+    }
   }
 
   // ---- epilogue.
@@ -691,7 +778,15 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
     for (int ps2 = 0; ps2 < PASSES; ++ps2) {
       const int row = row0 + i * 32 + ps2 * PIX_PER_PASS;
       const unsigned loff = (unsigned)row * row_bytes + lane_chunk;
-      if (rtile) {
+      if constexpr (X2) {
+        if (rtile) {
+          const unsigned char* rp = rtile + ((unsigned)(row < rows_valid ? row : rows_valid - 1) * row_bytes + lane_chunk);
+          float idv[8];
+          join16x8(*reinterpret_cast<const uint4*>(rp), *reinterpret_cast<const uint4*>(rp + 64), idv);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[ps2][q] += idv[q];
+        }
+      } else if (rtile) {
         uint4 rv;
         if constexpr (RES_PREFETCH) rv = rpre[i][ps2];
         else rv = *reinterpret_cast<const uint4*>(rtile + ((unsigned)(row < rows_valid ? row : rows_valid - 1) * row_bytes + lane_chunk));
@@ -712,7 +807,11 @@ __global__ __launch_bounds__(WM* WN * 64, min_waves_per_simd(PREC, WM, WN, MT, N
         for (int e = 0; e < OUT_CH; ++e) v[ps2][e] = __builtin_elementwise_maximum(v[ps2][e], 0.f);
       }
       uint4 o;
-      if constexpr (PREC == 0) {
+      if constexpr (X2) {
+        uint4 o1;
+        split16x8(v[ps2], o, o1);
+        if (row < rows_valid) *reinterpret_cast<uint4*>(ytile + loff + 64) = o1;
+      } else if constexpr (PREC == 0) {
         o.x = __builtin_bit_cast(unsigned, v[ps2][0]); o.y = __builtin_bit_cast(unsigned, v[ps2][1]);
         o.z = __builtin_bit_cast(unsigned, v[ps2][2]); o.w = __builtin_bit_cast(unsigned, v[ps2][3]);
       } else {
@@ -772,11 +871,25 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   9   128x128   4x2            32x64      2       70 KiB   2   (8 waves: short-K layers, where the
 //   10  128x64    4x2            32x32      2       48 KiB   3    serial prologue/epilogue code dominates
 //   11  256x128   4x4            64x32      2       96 KiB   1    and more waves run it in parallel)
+//   13  128x128   2x4            64x32      3       96 KiB   1   (8 waves; the widest tile of the f16x2 mode, whose three
+//                                                               accumulator sets allow wave tiles of 64x32 at most)
 //   12  256x256   4x4            64x64      2       128 KiB  1   (bf16: short-K layers at batch >= 2; the matrix pipe is
 //                                                               busier than with 8 waves, the clock lower: same TFLOP/s on
 //                                                               long-K layers, 2-5 % faster epilogue-heavy 1x1 layers)
 template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
+  if constexpr (PREC == 2) {             // f16x2: wave tiles of two 32x32 blocks at most (three accumulator sets)
+    switch (tile) {
+      case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);
+      case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, VAR>(a, s);
+      case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM, VAR>(a, s);
+      case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM, VAR>(a, s);
+      case 9: return launch_cfg<PREC, 4, 2, 1, 2, 3, STEM, VAR>(a, s);
+      case 10: return launch_cfg<PREC, 4, 2, 1, 1, 3, STEM, VAR>(a, s);
+      case 13: return launch_cfg<PREC, 2, 4, 2, 1, 3, STEM, VAR>(a, s);
+      default: return hipErrorInvalidValue;
+    }
+  } else
   switch (tile) {
     case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);
     case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);
@@ -795,12 +908,13 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
     case 12:
       if constexpr (PREC == 0) return hipErrorInvalidValue;
       else return launch_cfg<PREC, 4, 4, 2, 2, 2, STEM, VAR>(a, s);   // bf16 only (f32: 128-register budget)
+    case 13: return launch_cfg<PREC, 2, 4, 2, 1, 3, STEM, VAR>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128};
 
 }  // namespace
 
@@ -811,6 +925,7 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 bool conv_tile_ok(int precision, int tile, int Co) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
   if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
+  if (precision == 2 && !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || tile == 10 || tile == 13)) return false;
   return Co % kTileCols[tile] == 0;
 }
 
@@ -829,23 +944,29 @@ struct TileModel {
   double cu_flops_per_us;              // per-CU matrix rate the efficiencies refer to
   double eff[CONV_TILE_COUNT], ovh_us[CONV_TILE_COUNT], cb[CONV_TILE_COUNT];
 };
-constexpr TileModel kTileModel[2] = {
+constexpr TileModel kTileModel[3] = {
     // f32: 157.3 TF / 256 CUs
     {157.3e6 / 256.0,
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85},
-     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80},
+     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
     // bf16: against the 1 400 TF/s the chip sustains on this kernel (power-limited), / 256 CUs
     {1400.0e6 / 256.0,
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85},
-     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61},
-     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0}}};
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80},
+     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0},
+     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0}},
+    // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs;
+    // first guesses until scripts/fit_tile_model.py has data for this mode
+    {839.0e6 / 256.0,
+     {0.45, 0.45, 0.45, 0.45, 0.45, 0.45, 0.50, 0.42, 0.45, 0.50, 0.40, 0.45, 0.45, 0.55},
+     {3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.5, 2.5, 2.5, 3.0, 2.5, 3.0, 3.0, 3.5},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 }  // namespace
 
 int choose_conv_tile(int M, int Co, int K, int precision) {
-  if (precision != 0 && precision != 1) return -1;
+  if (precision < 0 || precision > 2) return -1;
   const TileModel& tm = kTileModel[precision];
-  const double eb = precision == 0 ? 4.0 : 2.0;
+  const double eb = precision == 1 ? 2.0 : 4.0;
   int best = -1;
   double best_cost = 0.0;
   for (int t = 0; t < CONV_TILE_COUNT; ++t) {
@@ -867,7 +988,7 @@ int choose_conv_tile(int M, int Co, int K, int precision) {
 }
 
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s) {
-  const int eb = precision == 0 ? 4 : 2;
+  const int eb = precision == 1 ? 2 : 4;
   if (a.M <= 0 || a.Co % 64 != 0 || a.ksteps <= 0 || a.x_bytes == 0 || a.x_bytes >= kOutOfRange || a.w_bytes == 0 ||
       a.w_bytes >= kOutOfRange)
     return hipErrorInvalidValue;
@@ -895,6 +1016,7 @@ hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream
   }
 #endif
   if (precision == 0) return a.stem ? launch_tile<0, true, 0>(a, tile, s) : launch_tile<0, false, 0>(a, tile, s);
+  if (precision == 2) return a.stem ? launch_tile<2, true, 0>(a, tile, s) : launch_tile<2, false, 0>(a, tile, s);
   if (a.stem) return launch_tile<1, true, 0>(a, tile, s);
   // bf16: the MFMA-heavy layers run on v_mfma_f32_16x16x32_bf16 (VAR 0: +4-5 % measured on the
   // head and layer4 3x3 convs, the chip holds a higher clock on it); the residual 1x1 layers keep

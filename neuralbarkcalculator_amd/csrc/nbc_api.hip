@@ -364,8 +364,7 @@ int nbc_destroy(nbc_ctx* c) {
 
 int nbc_attach_weights(nbc_ctx* c, const void* dev_blob, size_t bytes, int precision) {
   if (!c || !dev_blob) return set_error(NBC_ERR_INVALID, "nbc_attach_weights: null argument");
-  if (precision != NBC_PREC_FP32 && precision != NBC_PREC_BF16)
-    return set_error(NBC_ERR_INVALID, "nbc_attach_weights: unknown precision");
+  if (!known_precision(precision)) return set_error(NBC_ERR_INVALID, "nbc_attach_weights: unknown precision");
   PackedLayout L = packed_layout(precision);
   if (bytes < L.total_bytes) return set_error(NBC_ERR_INVALID, "nbc_attach_weights: blob smaller than the packed layout");
   if (reinterpret_cast<uintptr_t>(dev_blob) % 256 != 0)

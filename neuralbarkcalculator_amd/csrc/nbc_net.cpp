@@ -141,6 +141,46 @@ uint16_t f32_to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 
+uint16_t f32_to_f16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);          // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // >= 65520 rounds to infinity (and infinity itself)
+  if (a < 0x33000001u) return sign;                                 // <= 2^-25: rounds to zero (2^-25 is the tie to even 0)
+  const int e = (int)(a >> 23) - 127;                               // unbiased exponent, -24 .. 15 here
+  uint32_t m = (a & 0x007fffffu) | 0x00800000u;                     // 24-bit significand
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);                       // bits dropped (subnormal results drop more)
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) ++q;                 // round to nearest even (a carry runs into the exponent)
+  if (e >= -14) return (uint16_t)(sign | (uint16_t)(((uint32_t)(e + 15) << 10) + (q - 0x400u)));
+  return (uint16_t)(sign | (uint16_t)q);                            // subnormal (q == 0x400 is the smallest normal)
+}
+
+float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const int e = (h >> 10) & 0x1f;
+  const uint32_t m = h & 0x3ffu;
+  float out;
+  uint32_t u;
+  if (e == 0x1f) u = sign | 0x7f800000u | (m << 13);
+  else if (e != 0) u = sign | ((uint32_t)(e - 15 + 127) << 23) | (m << 13);
+  else {
+    out = (float)m * 5.9604644775390625e-08f;                       // m * 2^-24, exact
+    std::memcpy(&u, &out, 4);
+    u |= sign;
+  }
+  std::memcpy(&out, &u, 4);
+  return out;
+}
+
+void split_f16x2(float x, uint16_t* h0, uint16_t* h1) {
+  *h0 = f32_to_f16(x);
+  *h1 = f32_to_f16((x - f16_to_f32(*h0)) * 2048.0f);                // the difference is exact, the scaling a power of two
+}
+
 thread_local std::string g_last_error;
 
 int set_error(int code, const std::string& msg) {
@@ -192,14 +232,19 @@ int nbc_lowres_size(int H, int W, int* h, int* w) {
   return NBC_OK;
 }
 
+int nbc_split_f16x2(const float* x, size_t n, uint16_t* h0, uint16_t* h1) {
+  if (!x || !h0 || !h1) return set_error(NBC_ERR_INVALID, "nbc_split_f16x2: null argument");
+  for (size_t i = 0; i < n; ++i) split_f16x2(x[i], &h0[i], &h1[i]);
+  return NBC_OK;
+}
+
 size_t nbc_packed_weights_bytes(int precision) {
-  if (precision != NBC_PREC_FP32 && precision != NBC_PREC_BF16) return 0;
+  if (!known_precision(precision)) return 0;
   return packed_layout(precision).total_bytes;
 }
 
 int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob, size_t blob_bytes) {
-  if (precision != NBC_PREC_FP32 && precision != NBC_PREC_BF16)
-    return set_error(NBC_ERR_INVALID, "nbc_pack_weights: unknown precision");
+  if (!known_precision(precision)) return set_error(NBC_ERR_INVALID, "nbc_pack_weights: unknown precision");
   if (!tensors || n < 0 || !blob) return set_error(NBC_ERR_INVALID, "nbc_pack_weights: null argument");
   const PackedLayout L = packed_layout(precision);
   if (blob_bytes < L.total_bytes) return set_error(NBC_ERR_INVALID, "nbc_pack_weights: blob too small");
@@ -252,7 +297,15 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
             const float v = w[(((size_t)o * c.cin + ci) * c.k + kh) * c.k + kw];
             const size_t kidx = p.stem ? (size_t)(kh * 8 + kw) * p.cin_pad + ci      // stem: eight slots per kernel row
                                        : (size_t)(kh * c.k + kw) * p.cin_pad + ci;
-            if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;
+            if (precision == NBC_PREC_F16X2) {
+              // element kidx of the row in its f32-sized slot: 32-element groups of [h0 x 32][h1 x 32]; the stem's
+              // 16-byte tap is [h0 x 4][h1 x 4]
+              uint16_t h0, h1;
+              split_f16x2(v, &h0, &h1);
+              uint16_t* r16 = reinterpret_cast<uint16_t*>(row);
+              if (p.stem) { r16[(kidx / 4) * 8 + kidx % 4] = h0; r16[(kidx / 4) * 8 + 4 + kidx % 4] = h1; }
+              else { r16[(kidx / 32) * 64 + kidx % 32] = h0; r16[(kidx / 32) * 64 + 32 + kidx % 32] = h1; }
+            } else if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;
             else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
           }
     }

@@ -34,7 +34,10 @@ struct StateKey {
 const std::vector<ConvUnit>& conv_units();
 const std::vector<StateKey>& state_keys();
 
-inline int elem_bytes(int precision) { return precision == 0 ? 4 : 2; }
+// bytes per activation / weight element: f32 4, bf16 2, f16x2 4 (two f16 pieces; a 128-byte group holds 32 channels:
+// [h0 x 32][h1 x 32], so tensors, K-steps and LDS rows have the f32 mode's geometry)
+inline int elem_bytes(int precision) { return precision == 1 ? 2 : 4; }
+inline bool known_precision(int precision) { return precision >= 0 && precision <= 2; }
 
 // Packed layout of one conv unit inside the blob.
 struct PackedConv {

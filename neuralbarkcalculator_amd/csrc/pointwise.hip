@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "nbc_kernels.hpp"
+#include "split16.hpp"
 
 namespace nbc {
 namespace {
@@ -21,6 +22,14 @@ template <int PREC>
 __device__ __forceinline__ void store_pixel(void* y, size_t pix, float c0, float c1, float c2) {
   if constexpr (PREC == 0) {
     reinterpret_cast<float4*>(y)[pix] = make_float4(c0, c1, c2, 0.f);
+  } else if constexpr (PREC == 2) {               // [h0 x 4][h1 x 4]
+    _Float16 a0, a1, b0, b1, d0, d1;
+    split16(c0, a0, a1); split16(c1, b0, b1); split16(c2, d0, d1);
+    const auto bits = [](_Float16 h) { return (unsigned)__builtin_bit_cast(unsigned short, h); };
+    uint4 o;
+    o.x = bits(a0) | (bits(b0) << 16); o.y = bits(d0);
+    o.z = bits(a1) | (bits(b1) << 16); o.w = bits(d1);
+    reinterpret_cast<uint4*>(y)[pix] = o;
   } else {
     uint4 o;
     o.x = (unsigned)f32_to_bf16_bits(c0) | ((unsigned)f32_to_bf16_bits(c1) << 16);
@@ -69,13 +78,17 @@ __global__ void ingest_u8_kernel(const uint8_t* __restrict__ x, void* __restrict
 template <int PREC>
 __global__ __launch_bounds__(256) void maxpool_kernel(const void* __restrict__ x, void* __restrict__ y, int Hi, int Wi,
                                                       int chunk_shift, int Ho, int Wo) {
-  constexpr int EPC = PREC == 0 ? 4 : 8;          // elements per 16-byte chunk
+  // f16x2: a thread owns eight channels = the 16-byte h0 chunk j of a 128-byte group and its h1 chunk (j + 4);
+  // `chunks` counts those units (C / 8), a pixel is 2 * chunks 16-byte chunks long
+  constexpr int EPC = PREC == 0 ? 4 : 8;          // elements per thread
+  constexpr int CPU = PREC == 2 ? 2 : 1;          // 16-byte chunks per unit
   const int chunks = 1 << chunk_shift;
   const int e = blockIdx.x * 256 + threadIdx.x;   // (ox, chunk)
   const int ox = e >> chunk_shift, ch = e & (chunks - 1);
   const int oy = blockIdx.y, img = blockIdx.z;
   if (ox >= Wo) return;
-  const uint4* xv = static_cast<const uint4*>(x) + (size_t)img * Hi * Wi * chunks + ch;
+  const int ch16 = PREC == 2 ? (ch >> 2) * 8 + (ch & 3) : ch;     // the unit's first 16-byte chunk inside the pixel
+  const uint4* xv = static_cast<const uint4*>(x) + (size_t)img * Hi * Wi * chunks * CPU + ch16;
   float best[EPC];
 #pragma unroll
   for (int k = 0; k < EPC; ++k) best[k] = -__builtin_inff();
@@ -89,9 +102,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const void* __restrict__ x
       const int ix = ox * 2 - 1 + dx;
       const bool ok = oky && (unsigned)ix < (unsigned)Wi;
       const int cx = (unsigned)ix < (unsigned)Wi ? ix : ox * 2;
-      const uint4 v = xv[((size_t)cy * Wi + cx) * chunks];
+      const uint4 v = xv[((size_t)cy * Wi + cx) * chunks * CPU];
       float f[EPC];
-      if constexpr (PREC == 0) {
+      if constexpr (PREC == 2) {
+        join16x8(v, xv[((size_t)cy * Wi + cx) * chunks * CPU + 4], f);
+      } else if constexpr (PREC == 0) {
         f[0] = __builtin_bit_cast(float, v.x); f[1] = __builtin_bit_cast(float, v.y);
         f[2] = __builtin_bit_cast(float, v.z); f[3] = __builtin_bit_cast(float, v.w);
       } else {
@@ -107,7 +122,14 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const void* __restrict__ x
     }
   }
   uint4 o;
-  if constexpr (PREC == 0) {
+  if constexpr (PREC == 2) {   // the winner's pieces again: split(join(pair)) gives the pair back (an equal value at a tie)
+    uint4 o1;
+    split16x8(best, o, o1);
+    uint4* yp = static_cast<uint4*>(y) + (((size_t)img * Ho + oy) * Wo + ox) * chunks * CPU + ch16;
+    yp[0] = o;
+    yp[4] = o1;
+    return;
+  } else if constexpr (PREC == 0) {
     o.x = __builtin_bit_cast(unsigned, best[0]); o.y = __builtin_bit_cast(unsigned, best[1]);
     o.z = __builtin_bit_cast(unsigned, best[2]); o.w = __builtin_bit_cast(unsigned, best[3]);
   } else {          // inputs were bf16, so the max is exactly representable: truncate
@@ -142,21 +164,30 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x
   const int first = (blockIdx.x * 4 + wave) * PIX_PER_WAVE;
   if (counts_zero && blockIdx.x == 0 && threadIdx.x < ncounts) counts_zero[threadIdx.x] = 0ull;   // for the next launch
   // the wave's 8 pixel rows are requested together (one memory round trip), then reduced one by one
-  constexpr int VPP = PREC == 0 ? 2 : 1;                  // 16-byte loads per lane and pixel
+  constexpr int VPP = PREC == 1 ? 1 : 2;                  // 16-byte loads per lane and pixel
   uint4 raw[PIX_PER_WAVE][VPP];
 #pragma unroll
   for (int q = 0; q < PIX_PER_WAVE; ++q) {
     const int m = min(first + q, M - 1);
-    const uint4* xp = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(x) +
-                                                     ((size_t)m * CIN + lane * 8) * (PREC == 0 ? 4 : 2));
+    if constexpr (PREC == 2) {      // channels 8l .. 8l+7: h0 chunk l % 4 of group l / 4, and its h1 chunk 64 bytes on
+      const uint4* xp = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(x) + (size_t)m * CIN * 4 +
+                                                       (lane >> 2) * 128 + (lane & 3) * 16);
+      raw[q][0] = xp[0];
+      raw[q][VPP - 1] = xp[4];
+    } else {
+      const uint4* xp = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(x) +
+                                                       ((size_t)m * CIN + lane * 8) * (PREC == 0 ? 4 : 2));
 #pragma unroll
-    for (int k = 0; k < VPP; ++k) raw[q][k] = xp[k];
+      for (int k = 0; k < VPP; ++k) raw[q][k] = xp[k];
+    }
   }
 #pragma unroll
   for (int q = 0; q < PIX_PER_WAVE; ++q) {
     const int m = first + q;
     float f[8];
-    if constexpr (PREC == 0) {
+    if constexpr (PREC == 2) {
+      join16x8(raw[q][0], raw[q][VPP - 1], f);
+    } else if constexpr (PREC == 0) {
       const uint4 a = raw[q][0], b = raw[q][VPP - 1];
       f[0] = __builtin_bit_cast(float, a.x); f[1] = __builtin_bit_cast(float, a.y);
       f[2] = __builtin_bit_cast(float, a.z); f[3] = __builtin_bit_cast(float, a.w);
@@ -413,7 +444,10 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restric
     const size_t img = pix / HW, p = pix - img * HW;
     float v;
     if constexpr (PREC == 0) v = static_cast<const float*>(x)[i];
-    else v = bf16_bits_to_f32(static_cast<const unsigned short*>(x)[i]);
+    else if constexpr (PREC == 2) {
+      const _Float16* hp = static_cast<const _Float16*>(x) + pix * (size_t)C * 2 + (c >> 5) * 64 + (c & 31);
+      v = join16(hp[0], hp[32]);
+    } else v = bf16_bits_to_f32(static_cast<const unsigned short*>(x)[i]);
     y[(img * C + c) * (size_t)HW + p] = v;
   }
 }
@@ -536,6 +570,7 @@ hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int p
   const int HW = H * W;
   dim3 grid((HW + 511) / 512, N);
   if (precision == 0) hipLaunchKernelGGL(ingest_f32_kernel<0>, grid, dim3(256), 0, s, x, y, HW);
+  else if (precision == 2) hipLaunchKernelGGL(ingest_f32_kernel<2>, grid, dim3(256), 0, s, x, y, HW);
   else hipLaunchKernelGGL(ingest_f32_kernel<1>, grid, dim3(256), 0, s, x, y, HW);
   return hipGetLastError();
 }
@@ -547,6 +582,9 @@ hipError_t launch_ingest_u8(const uint8_t* x, void* y, int N, int H, int W, cons
   if (precision == 0)
     hipLaunchKernelGGL(ingest_u8_kernel<0>, dim3(g), dim3(256), 0, s, x, y, total, mean[0], mean[1],
                        mean[2], stdv[0], stdv[1], stdv[2]);
+  else if (precision == 2)
+    hipLaunchKernelGGL(ingest_u8_kernel<2>, dim3(g), dim3(256), 0, s, x, y, total, mean[0], mean[1],
+                       mean[2], stdv[0], stdv[1], stdv[2]);
   else
     hipLaunchKernelGGL(ingest_u8_kernel<1>, dim3(g), dim3(256), 0, s, x, y, total, mean[0], mean[1],
                        mean[2], stdv[0], stdv[1], stdv[2]);
@@ -556,13 +594,14 @@ hipError_t launch_ingest_u8(const uint8_t* x, void* y, int N, int H, int W, cons
 hipError_t launch_maxpool3x3s2(const void* x, void* y, int N, int Hi, int Wi, int C, int Ho, int Wo,
                                int precision, hipStream_t s) {
   const int epc = precision == 0 ? 4 : 8;
-  if (C % epc != 0) return hipErrorInvalidValue;
+  if (C % epc != 0 || (precision == 2 && C % 32 != 0)) return hipErrorInvalidValue;
   const int chunks = C / epc;
   int shift = 0;
   while ((1 << shift) < chunks) ++shift;
   if ((1 << shift) != chunks || chunks > 256 || Ho > 65535 || N > 65535) return hipErrorInvalidValue;   // C = 64 on this path
   dim3 grid((Wo * chunks + 255) / 256, Ho, N);
   if (precision == 0) hipLaunchKernelGGL(maxpool_kernel<0>, grid, dim3(256), 0, s, x, y, Hi, Wi, shift, Ho, Wo);
+  else if (precision == 2) hipLaunchKernelGGL(maxpool_kernel<2>, grid, dim3(256), 0, s, x, y, Hi, Wi, shift, Ho, Wo);
   else hipLaunchKernelGGL(maxpool_kernel<1>, grid, dim3(256), 0, s, x, y, Hi, Wi, shift, Ho, Wo);
   return hipGetLastError();
 }
@@ -573,6 +612,7 @@ hipError_t launch_head1x1(const void* x, const float* w, const float* bias, floa
   const int M = N * hw;
   const int blocks = (M + 31) / 32;           // 4 waves x 8 pixels
   if (precision == 0) hipLaunchKernelGGL(head1x1_kernel<0>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
+  else if (precision == 2) hipLaunchKernelGGL(head1x1_kernel<2>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
   else hipLaunchKernelGGL(head1x1_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
   return hipGetLastError();
 }
@@ -624,6 +664,7 @@ hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W,
   const size_t total = (size_t)N * H * W * C;
   const int g = grid_for(total, 256);
   if (precision == 0) hipLaunchKernelGGL(nhwc_to_nchw_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
+  else if (precision == 2) hipLaunchKernelGGL(nhwc_to_nchw_kernel<2>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
   else hipLaunchKernelGGL(nhwc_to_nchw_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
   return hipGetLastError();
 }

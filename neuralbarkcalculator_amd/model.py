@@ -22,7 +22,7 @@ from . import _lib
 from .topology import NUM_CLASSES, out_hw
 
 _PRECISIONS = {"fp32": _lib.PREC_FP32, "f32": _lib.PREC_FP32, "float32": _lib.PREC_FP32,
-               "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}
+               "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16, "f16x2": _lib.PREC_F16X2}
 
 
 def _as_numpy(v) -> np.ndarray:
@@ -69,8 +69,10 @@ def pack_state_dict(state_dict: Mapping[str, object], precision: str = "fp32") -
 class FCNResNet50:
     """MI355X-native ``fcn_resnet50`` (3 classes, output stride 8, bicubic upsample), eval mode.
 
-    precision: ``"fp32"`` -- f32 MFMA, the parity mode; ``"bf16"`` -- bf16 MFMA with f32
-    accumulation and f32 BatchNorm epilogue, the throughput mode.
+    precision: ``"fp32"`` -- f32 MFMA, the parity mode; ``"f16x2"`` -- f32-grade on the f16 matrix pipe: every f32
+    value kept as two f16 pieces, three exact f16 products per product, f32 two-level sums (include/nbc.h,
+    NBC_PREC_F16X2; same tolerances as "fp32" in the tests); ``"bf16"`` -- bf16 MFMA with f32 accumulation and f32
+    BatchNorm epilogue, the throughput mode.
     """
 
     def __init__(self, precision: str = "fp32"):

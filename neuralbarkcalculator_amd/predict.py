@@ -632,7 +632,7 @@ def main(argv=None):
     ap.add_argument("--exclude_nodes", action="store_true")
     ap.add_argument("--only_preprocess", action="store_true")
     ap.add_argument("--model_path", default="./best_model.pt")       # predict.py:57
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--precision", choices=["fp32", "f16x2", "bf16"], default="fp32")
     ap.add_argument("--no_small_zones", action="store_true")
     ap.add_argument("--gpus", type=int, default=1, help="shard the folder over N GPUs of this node (one process each, RCCL)")
     ap.add_argument("--batch", type=int, default=None, help="frames of equal size per forward (default 2 in fp32, 8 in bf16)")

@@ -97,12 +97,44 @@ def _bf16_to_f32(u16):
     return (u16.astype(np.uint32) << 16).view(np.float32)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def _join_f16x2(raw_u8, row_elems, group):
+    """A packed f16x2 row -> (h0, h1) as float32 arrays in element order: groups of `group` elements are stored as
+    [h0 x group][h1 x group] (group = 32 channels, or 4 for the stem's 16-byte tap)."""
+    h = raw_u8.view(np.float16).reshape(-1, row_elems // group, 2, group)
+    return (h[:, :, 0, :].reshape(-1, row_elems).astype(np.float32), h[:, :, 1, :].reshape(-1, row_elems).astype(np.float32))
+
+
+def test_split_f16x2_is_numpy_float16_rounding(built_lib):
+    """nbc_split_f16x2 (the host side of NBC_PREC_F16X2): h0 = float16(x) rounded to nearest even with subnormals,
+    overflow to infinity from 65520 on; h1 = float16((x - h0) * 2^11).  Against numpy's binary16 on magnitudes from
+    subnormal to overflow, special values and 300 000 random bit patterns; and h0 + h1 / 2^11 gives x back to 2^-24."""
+    rng = np.random.default_rng(0)
+    parts = [rng.standard_normal(100000).astype(np.float32) * np.float32(s) for s in (1, 1e-3, 1e-5, 1e-7, 100, 6e4, 1e5)]
+    parts.append(np.array([0, -0.0, 65504, 65519.996, 65520, 65536, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.0001, 2.0 ** -14,
+                           np.inf, -np.inf, np.nan, 6.1e-5, 6.0975e-5, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11], dtype=np.float32))
+    parts.append(rng.integers(0, 2 ** 32, 300000, dtype=np.uint64).astype(np.uint32).view(np.float32))
+    x = np.concatenate(parts)
+    h0 = np.zeros(x.size, np.uint16)
+    h1 = np.zeros(x.size, np.uint16)
+    assert built_lib.nbc_split_f16x2(x.ctypes.data, x.size, h0.ctypes.data, h1.ctypes.data) == 0
+    with np.errstate(all="ignore"):
+        w0 = x.astype(np.float16)
+        w1 = ((x - w0.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    for got, want in ((h0, w0), (h1, w1)):
+        same = (want.view(np.uint16) == got) | (np.isnan(want) & np.isnan(got.view(np.float16)))
+        assert same.all(), x[~same][:5]
+    normal = np.isfinite(x) & (np.abs(x) < 65504) & (np.abs(x) > 1e-3)
+    back = h0.view(np.float16).astype(np.float64) + h1.view(np.float16).astype(np.float64) / 2048.0
+    rel = np.abs(back[normal] - x[normal].astype(np.float64)) / np.abs(x[normal].astype(np.float64))
+    assert rel.max() <= 2.0 ** -23, rel.max()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "f16x2"])
 def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
     blob = pack_state_dict(sd_np, precision)
-    prec = 0 if precision == "fp32" else 1
+    prec = {"fp32": 0, "bf16": 1, "f16x2": 2}[precision]
     assert blob.nbytes == built_lib.nbc_packed_weights_bytes(prec)
-    eb = 4 if prec == 0 else 2
+    eb = 2 if prec == 1 else 4
     off = 0
 
     def align(v):
@@ -123,8 +155,11 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
             cin_pad, ksteps = u.cin, u.k * u.k * u.cin * eb // 128
         row = ksteps * 128 // eb
         raw = blob[off: off + u.cout * ksteps * 128]
-        got = raw.view(np.float32) if prec == 0 else _bf16_to_f32(raw.view(np.uint16))
-        got = got.reshape(u.cout, row)
+        if prec == 2:        # two f16 pieces per element in the f32 mode's geometry
+            g0, g1 = _join_f16x2(raw, row, 4 if u.cin == 3 else 32)
+        else:
+            got = raw.view(np.float32) if prec == 0 else _bf16_to_f32(raw.view(np.uint16))
+            got = got.reshape(u.cout, row)
         want = np.zeros((u.cout, row), np.float32)
         khkwci = w.transpose(0, 2, 3, 1)                       # [O][kh][kw][I]
         for tap in range(u.k * u.k):
@@ -134,7 +169,12 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
             want[:, slot * cin_pad: slot * cin_pad + u.cin] = khkwci[:, tap // u.k, tap % u.k, :]
         if prec == 1:
             want = torch.from_numpy(want).to(torch.bfloat16).float().numpy()   # RNE like the packer
-        np.testing.assert_array_equal(got, want, err_msg=u.name)
+        if prec == 2:
+            w0 = want.astype(np.float16).astype(np.float32)
+            np.testing.assert_array_equal(g0, w0, err_msg=u.name)
+            np.testing.assert_array_equal(g1, ((want - w0) * np.float32(2048)).astype(np.float16).astype(np.float32), err_msg=u.name)
+        else:
+            np.testing.assert_array_equal(got, want, err_msg=u.name)
         off = align(off + u.cout * ksteps * 128)
         scale = blob[off: off + u.cout * 4].view(np.float32)
         off = align(off + u.cout * 4)
@@ -172,16 +212,17 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
 def test_default_conv_tile_cost_model(built_lib):
     """Host logic of the per-layer default tile (csrc/conv_igemm_dma.hip, choose_conv_tile): a valid tile for the
     precision and channel count, and the choices that matter most, where whole rounds of blocks on 256 CUs decide."""
-    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256]
-    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256]
+    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128]
+    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128]
     f = built_lib.nbc_default_conv_tile
-    for prec in (0, 1):
+    for prec in (0, 1, 2):
         for co in (64, 128, 256, 512, 1024, 2048):
             for m in (64, 1000, 8448, 9984, 16384, 65536, 131072, 524288):
                 for k in (64, 576, 2048, 18432):
                     t = f(m, co, k, prec)
-                    assert 0 <= t < 13 and co % cols[t] == 0
+                    assert 0 <= t < 14 and co % cols[t] == 0
                     assert not (prec == 0 and t in (3, 12))            # f32 has no 256x256 tile
+                    assert prec != 2 or t in (0, 6, 7, 8, 9, 10, 13)   # f16x2: wave tiles of 64x32 at most
     assert f(16384, 96, 64, 0) == -1 and f(16384, 512, 64, 7) == -1 and f(0, 512, 64, 0) == -1
     blocks = lambda t, m, co: -(-m // rows[t]) * (co // cols[t])
     # the head conv (3x3, 2048 -> 512) in f32 at 1024x1024: 16 384 pixels, one 256x128 / 128x256 tile per CU

@@ -32,9 +32,10 @@ DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def gpu_fp32(built_lib, sd_np):
-    return FCNResNet50("fp32").load_state_dict(sd_np).to(DEV)
+@pytest.fixture(scope="module", params=["fp32", "f16x2"])
+def gpu_fp32(request, built_lib, sd_np):
+    """Both f32-grade modes under the same tolerances (see tests/test_gpu_parity.py)."""
+    return FCNResNet50(request.param).load_state_dict(sd_np).to(DEV)
 
 
 @pytest.fixture(scope="module")

@@ -34,9 +34,11 @@ BF16_MARGIN_BAND = 0.10
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def gpu_fp32(built_lib, sd_np):
-    return FCNResNet50("fp32").load_state_dict(sd_np).to(DEV)
+@pytest.fixture(scope="module", params=["fp32", "f16x2"])
+def gpu_fp32(request, built_lib, sd_np):
+    """The f32-grade modes, under the SAME tolerances: "fp32" (v_mfma_f32_32x32x2_f32) and "f16x2" (every f32 value as
+    two f16 pieces, three exact f16 products per product on v_mfma_f32_16x16x32_f16, f32 two-level sums)."""
+    return FCNResNet50(request.param).load_state_dict(sd_np).to(DEV)
 
 
 @pytest.fixture(scope="module")
@@ -251,7 +253,7 @@ def test_errors_are_python_exceptions(gpu_fp32):
         FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
 
 
-@pytest.mark.parametrize("tile", list(range(13)))
+@pytest.mark.parametrize("tile", list(range(14)))
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, tile):
     """Each conv kernel instantiation (every tile shape of the LDS-DMA kernel) against
@@ -286,12 +288,12 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
     try:
         model.set_conv_tile(-1)
         base = model(x)
-        for tile in range(13):
+        for tile in range(14):
             model.set_conv_tile(tile)
             assert torch.equal(model(x), base), f"tile {tile} changes the logits"
         model.set_conv_tile(-1)
         tiles = model.autotune(x, reps=2)
-        assert len(tiles) == 54 and all(0 <= t < 13 for t in tiles)
+        assert len(tiles) == 54 and all(0 <= t < 14 for t in tiles)
         assert torch.equal(model(x), base)
     finally:
         model.set_conv_tile(-1)
