@@ -26,7 +26,7 @@ import json
 import os
 import statistics
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "f16x2": 2500.0 / 3.0}   # f16x2: algorithmic FLOPs, three f16 MFMA FLOPs each
 HBM = 6.29e12
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for the two bench configurations, on one GPU box:
 #   gpurun --timeout 1100 -- 'bash scripts/profile_round.sh'   ->  gpurun_out/profile_round/
-# Per configuration (f32 batch 1 = the headline; bf16 batch 8 = configs[2]):
+# Per configuration (f16x2 batch 1 = the headline; f32 MFMA batch 1; bf16 batch 8 = configs[2]):
 #   1. a plain bench run measures the per-layer tiles once and saves them (tiles.json);
 #   2. rocprofv3 --kernel-trace --stats of the SAME bench command with those tiles installed, so that the
 #      trace and the --stats summary hold nothing but warm-up and timed forwards (no autotune launches);
@@ -14,11 +14,12 @@ out=$root/gpurun_out/profile_round
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 K=${K:-12}; W=${W:-3}
-python3 $root/bench.py --streams 1 --steps $K --warmup $W --bf16-steps $K --bf16-streams 1 --no-cpu-baseline --no-parity --save-tiles $out/tiles.json > $out/bench_tiles.json 2> $out/bench_tiles.err
-for cfg in "fp32 1 f32" "bf16 8 bf16"; do
+python3 $root/bench.py --streams 1 --steps $K --warmup $W --bf16-steps $K --bf16-streams 1 --f32-steps $K --f32-streams 1 --no-cpu-baseline --no-parity --save-tiles $out/tiles.json > $out/bench_tiles.json 2> $out/bench_tiles.err
+cfgs=("f16x2 1 f16x2" "fp32 1 f32" "bf16 8 bf16")
+for cfg in "${cfgs[@]}"; do
   set -- $cfg; prec=$1; batch=$2; dt=$3
   d=$out/${dt}_b${batch}; mkdir -p $d
-  common="--precision $prec --batch $batch --streams 1 --steps $K --warmup $W --no-bf16-leg --no-cpu-baseline --no-parity --tiles-file $out/tiles.json"
+  common="--precision $prec --batch $batch --streams 1 --steps $K --warmup $W --no-bf16-leg --no-f32-leg --no-cpu-baseline --no-parity --tiles-file $out/tiles.json"
   rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 $root/bench.py $common --dump-ops $d/ops.json > $d/trace.log 2>&1
   echo "trace $cfg done"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 $root/bench.py $common --no-op-events > $d/fetch.log 2>&1
@@ -31,4 +32,4 @@ for cfg in "fp32 1 f32" "bf16 8 bf16"; do
   rm -rf $d/fetch $d/write $d/mfma  # counter CSVs are large; the table keeps what is needed
   find $d/trace -name "*kernel_trace.csv" -exec gzip -9 {} \;
 done
-head -40 $out/table_f32_b1.log
+head -40 $out/table_f16x2_b1.log

@@ -32,22 +32,31 @@ def check_roofline(r, peak):
 
 
 def test_default_bench_line(built_lib):
-    """The driver's command shape: the headline is configs[1] in the reference's arithmetic (f32)."""
+    """The driver's command shape: the headline is configs[1] in the f32-grade f16x2 mode (same parity bounds as the f32
+    MFMA mode, which rides along as its own object), configs[2] (bf16, batch 8) as another."""
     d = run_bench("--steps", "8", "--warmup", "2")
     assert d["metric"].startswith("1024x1024 images/sec") and d["unit"] == "images/s"
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["rccl_ranks"] == 1
     assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # batch 1, one rank
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["dtype"] == "f16x2" and "f32-grade" in d["dtype_note"] and d["data"] == "synthetic"
     assert d["config"]["workload"].startswith("configs[1]") and "model" not in d["config"]
-    assert d["config"]["batch"] == 1 and d["config"]["precision"] == "fp32"
-    check_roofline(d["roofline"], 157.3)
+    assert d["config"]["batch"] == 1 and d["config"]["precision"] == "f16x2"
+    check_roofline(d["roofline"], 2500.0 / 3.0)
+    assert d["roofline"]["mfma_flops_per_algorithmic_flop"] == 3
     c = d["cpu_baseline"]
     assert c["value"] > 0 and c["unit"] == "images/s" and c["cores"] >= 1 and c["kind"] == "port" and isinstance(c["sample"], str)
     assert d["value"] > 50 * c["value"]
-    # f32 mode: the label mask equals the oracle's but for exact logit ties (a handful of 1 048 576 pixels)
-    assert d["parity"]["precision"] == "fp32" and d["parity"]["label_mismatches"] <= 20
-    assert d["parity"]["max_oracle_margin_at_mismatch"] <= 1e-4 * d["parity"]["oracle_logit_range"]
+    # the f32-grade modes: the label mask equals the oracle's but for exact logit ties (at most 4 per megapixel, the bound of
+    # tests/test_gpu_parity.py), low-res logits within 5e-6 of the oracle's logit range
+    for par, prec in ((d["parity"], "f16x2"), (d["f32_mfma_batch1"]["parity"], "fp32")):
+        assert par["precision"] == prec and par["label_mismatches"] <= 4 and par["pixels"] == 1024 * 1024
+        assert par["max_oracle_margin_at_mismatch"] <= 1e-5 * par["oracle_logit_range"]
+        assert par["max_lowres_logit_err_over_oracle_range"] <= 5e-6
+    f = d["f32_mfma_batch1"]
+    assert f["config"]["workload"].startswith("configs[1]") and f["dtype"] == "f32" and f["value"] > 0
+    check_roofline(f["roofline"], 157.3)
+    assert d["value"] > 1.5 * f["value"]            # measured 2.2-2.3x
     # configs[2] rides along as its own object with its own parity and roofline, never as the headline
     b = d["bf16_batch8"]
     assert b["config"]["workload"].startswith("configs[2]") and b["config"]["batch"] == 8 and b["dtype"] == "bf16"

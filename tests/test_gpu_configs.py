@@ -10,7 +10,7 @@ Tolerances (written here, used below):
     LOGIT_RTOL_FP32 of the logit range; labels IDENTICAL to the float64 labels wherever the float64 top-2
     margin exceeds twice the measured f32 logit error; wherever the HIP f32 labels differ from the CPU f32
     oracle's, the float64 result says which side is right, and the tally is reported (and written to
-    gpurun_out/fp64_adjudication.json when that directory exists).
+    gpurun_out/fp64_adjudication_<mode>.json when that directory exists), for both f32-grade modes (fp32, f16x2).
 """
 import json
 import os
@@ -171,7 +171,7 @@ def test_fp32_label_flips_adjudicated_by_float64(oracle_model, oracle_f64, gpu_f
     n_flip = int(flip.sum())
     hip_right = int((labels[flip] == lab64[flip]).sum())
     cpu_right = int((lab32[flip] == lab64[flip]).sum())
-    report = {"case": name, "pixels": int(labels.numel()), "logit_range": scale,
+    report = {"case": name, "mode": gpu_fp32.precision, "pixels": int(labels.numel()), "logit_range": scale,
               "max_abs_logit_err_hip_f32_vs_f64": err_hip, "max_abs_logit_err_cpu_f32_vs_f64": err_cpu,
               "labels_hip_f32_vs_cpu_f32_oracle_differ": n_flip,
               "of_those_hip_agrees_with_f64": hip_right, "of_those_cpu_oracle_agrees_with_f64": cpu_right,
@@ -185,7 +185,7 @@ def test_fp32_label_flips_adjudicated_by_float64(oracle_model, oracle_f64, gpu_f
     assert n_flip <= int((~clear).sum())
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
-        path = os.path.join(out, "fp64_adjudication.json")
+        path = os.path.join(out, "fp64_adjudication_%s.json" % gpu_fp32.precision)
         prev = json.load(open(path)) if os.path.exists(path) else {}
         prev[name] = report
         json.dump(prev, open(path, "w"), indent=1)
