@@ -13,20 +13,29 @@ import math
 import random
 import sys
 
-ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256]
-COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256]
-PEAK = {"fp32": 157.3e12 / 256 * 1e-3, "bf16": 1400e12 / 256 * 1e-3}          # FLOPs per ms per CU
+ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128]
+COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128]
+NT = len(ROWS)
+# FLOPs per ms per CU the efficiencies refer to (f16x2: algorithmic FLOPs, three f16 MFMA FLOPs each: 2 517 / 3)
+PEAK = {"fp32": 157.3e12 / 256 * 1e-3, "bf16": 1400e12 / 256 * 1e-3, "f16x2": 839e12 / 256 * 1e-3}
 BYTE_MS = 1.0 / (50e9 * 1e-3)                                                # ms per byte at 50 GB/s
 MODEL = {
-    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85],
-                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * 13),
-    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85],
-                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61],
-                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0]),
+    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80],
+                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * NT),
+    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80],
+                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0],
+                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0]),
+    "f16x2": dict(eff=[0.45, 0.45, 0.45, 0.45, 0.45, 0.45, 0.50, 0.42, 0.45, 0.50, 0.40, 0.45, 0.45, 0.55, 0.60],
+                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.5, 2.5, 2.5, 3.0, 2.5, 3.0, 3.0, 3.5, 3.5], cb=[0.0] * NT),
 }
+F16X2_TILES = (0, 6, 7, 8, 9, 10, 13, 14)
 
 
 def tile_ok(prec, t, co):
+    if prec == "f16x2" and t not in F16X2_TILES:
+        return False
+    if prec != "f16x2" and t == 14:
+        return False
     return not (prec == "fp32" and t in (3, 12)) and co % COLS[t] == 0
 
 
@@ -52,13 +61,13 @@ def load(path):
             ho, wo = out_hw(name, h)
             M = b * ho * wo
             rows.append(dict(co=co, M=M, K=c["flops"][i] / (2.0 * M * co), default_ms=c["default_ms"][i], tuned=c["tuned_tiles"][i],
-                             ts={t: c["per_tile"][str(t)][i] for t in range(13) if tile_ok(prec, t, co)}))
+                             ts={t: c["per_tile"][str(t)][i] for t in range(NT) if str(t) in c["per_tile"] and tile_ok(prec, t, co)}))
         res[key] = rows
     return res
 
 
 def pick(r, prec, p):
-    eb = 4 if prec == "fp32" else 2
+    eb = 2 if prec == "bf16" else 4
     best, best_cost = None, 0.0
     for t in sorted(r["ts"]):
         blocks = math.ceil(r["M"] / ROWS[t]) * (r["co"] // COLS[t])
@@ -89,7 +98,7 @@ def regret(data, prec, p, verbose=False):
 
 def fit(data, prec, iters=8000, seed=1, lam=0.002):
     random.seed(seed)
-    p = dict(eff=[0.85] * 13, ovh=[4.0] * 13, cb=[0.0 if prec == "fp32" else 1.0] * 13)
+    p = dict(eff=[0.5 if prec == "f16x2" else 0.85] * NT, ovh=[3.0 if prec == "f16x2" else 4.0] * NT, cb=[1.0 if prec == "bf16" else 0.0] * NT)
     prior = {k: list(v) for k, v in p.items()}
 
     def score(q):
@@ -99,10 +108,10 @@ def fit(data, prec, iters=8000, seed=1, lam=0.002):
     best = score(p)
     for _ in range(iters):
         q = {k: list(v) for k, v in p.items()}
-        t, u = random.randrange(13), random.random()
+        t, u = random.randrange(NT), random.random()
         if u < 0.4:
-            q["eff"][t] = min(1.0, max(0.45, q["eff"][t] + random.gauss(0, 0.05)))
-        elif u < 0.7 or prec == "fp32":
+            q["eff"][t] = min(1.0, max(0.2, q["eff"][t] + random.gauss(0, 0.05)))
+        elif u < 0.7 or prec != "bf16":
             q["ovh"][t] = min(12.0, max(0.0, q["ovh"][t] + random.gauss(0, 1.0)))
         else:
             q["cb"][t] = min(4.0, max(0.0, q["cb"][t] + random.gauss(0, 0.2)))
@@ -118,7 +127,9 @@ def main():
     everything = {}
     for s in sets:
         everything.update(s)
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "f16x2"):
+        if not any(k.startswith(prec) for k in everything):
+            continue
         if "--fit" in sys.argv:
             if len(sets) == 2:
                 for a, b, tag in ((sets[0], sets[1], "first -> second"), (sets[1], sets[0], "second -> first")):

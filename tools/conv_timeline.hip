@@ -29,8 +29,8 @@ int main(int argc, char** argv) {
   const int Hi = atoi(argv[1]), Wi = atoi(argv[2]), Ci = atoi(argv[3]), Co = atoi(argv[4]);
   const int K = atoi(argv[5]), dil = atoi(argv[6]), res = atoi(argv[7]), tile = atoi(argv[8]);
   if (Hi < 1 || Wi < 1 || Ci % 64 || Co % 64 || (K != 1 && K != 3) || tile < 0 || tile >= nbc::CONV_TILE_COUNT) return 2;
-  const int prec = argc > 10 ? atoi(argv[10]) : 1;          // 1 = bf16 (default), 0 = f32
-  const int eb = prec == 0 ? 4 : 2;
+  const int prec = argc > 10 ? atoi(argv[10]) : 1;          // 1 = bf16 (default), 0 = f32, 2 = f16x2
+  const int eb = prec == 1 ? 2 : 4;
   const int M = Hi * Wi, ksteps = K * K * Ci * eb / 128;
   const size_t xb = (size_t)M * Ci * eb, wb = (size_t)Co * ksteps * 128, yb = (size_t)M * Co * eb;
   std::vector<unsigned short> hx(xb / 2), hw(wb / 2), hr(yb / 2);
@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
   unsigned long long t0 = ~0ull, t1 = 0;
   for (int b = 0; b < nblk; ++b) { t0 = std::min(t0, h[b * 64]); t1 = std::max(t1, h[b * 64 + 6]); }
   std::printf("shape %dx%d Ci %d Co %d k%d d%d res %d %s tile %d (%dx%d): %d blocks, %d K-steps | %.1f us/launch back-to-back, %.0f TF | stamped span %.1f us\n",
-              Hi, Wi, Ci, Co, K, dil, res, prec == 1 ? "bf16" : "f32", tile, nbc::conv_tile_rows(tile), nbc::conv_tile_cols(tile), nblk, ksteps, us,
+              Hi, Wi, Ci, Co, K, dil, res, prec == 1 ? "bf16" : prec == 2 ? "f16x2" : "f32", tile, nbc::conv_tile_rows(tile), nbc::conv_tile_cols(tile), nblk, ksteps, us,
               flops / us * 1e-6, (t1 - t0) * 0.01);
   auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
   const char* names[10] = {"start (since first block)", "address set-up done", "prologue issued", "first K-step landed",
@@ -124,7 +124,9 @@ int main(int argc, char** argv) {
     std::vector<double> ghz, util, fvm, fbar;
     double wvm[16] = {0}, wbar[16] = {0}; int wn = 0;
     // MAC per K-step of the tile / (4 SIMDs x MAC per clock per SIMD: 512 bf16, 32 f32)
-    const double mfma_cyc_per_step = (double)nbc::conv_tile_rows(tile) * nbc::conv_tile_cols(tile) * (prec == 1 ? 64.0 / (4 * 512.0) : 32.0 / (4 * 32.0));
+    // (f16x2: 32 channels per K-step, three f16 products each)
+    const double mfma_cyc_per_step = (double)nbc::conv_tile_rows(tile) * nbc::conv_tile_cols(tile) *
+                                     (prec == 1 ? 64.0 / (4 * 512.0) : prec == 2 ? 3.0 * 32.0 / (4 * 512.0) : 32.0 / (4 * 32.0));
     for (int b = 0; b < nblk; ++b) {
       const double dt = (double)(h[b * 64 + 3] - h[b * 64 + 2]), dc = (double)(h[b * 64 + 12] - h[b * 64 + 11]);
       if (h[b * 64 + 2] == 0 || dt < 50) continue;
