@@ -999,11 +999,12 @@ constexpr TileModel kTileModel[3] = {
      {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80},
      {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0},
      {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0}},
-    // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs;
-    // first guesses until scripts/fit_tile_model.py has data for this mode
+    // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs; fitted to
+    // eight (batch, height) cases (profiles/r03_tile_model_data_f16x2_*.json, r03_tile_model_fit_f16x2.log): 1.2-2.9 % from
+    // the per-layer best
     {839.0e6 / 256.0,
-     {0.45, 0.45, 0.45, 0.45, 0.45, 0.45, 0.50, 0.42, 0.45, 0.50, 0.40, 0.45, 0.45, 0.55, 0.60},
-     {3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.5, 2.5, 2.5, 3.0, 2.5, 3.0, 3.0, 3.5, 3.5},
+     {0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.54},
+     {3, 3, 3, 3, 3, 3, 3.403, 1.77, 1.494, 2.995, 1.691, 3, 3, 3, 3.673},
      {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 }  // namespace
 

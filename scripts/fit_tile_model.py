@@ -25,8 +25,8 @@ MODEL = {
     "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80],
                  ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0],
                  cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0]),
-    "f16x2": dict(eff=[0.45, 0.45, 0.45, 0.45, 0.45, 0.45, 0.50, 0.42, 0.45, 0.50, 0.40, 0.45, 0.45, 0.55, 0.60],
-                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.5, 2.5, 2.5, 3.0, 2.5, 3.0, 3.0, 3.5, 3.5], cb=[0.0] * NT),
+    "f16x2": dict(eff=[0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.54],
+                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.403, 1.77, 1.494, 2.995, 1.691, 3.0, 3.0, 3.0, 3.673], cb=[0.0] * NT),
 }
 F16X2_TILES = (0, 6, 7, 8, 9, 10, 13, 14)
 
