@@ -16,8 +16,11 @@ from neuralbarkcalculator_amd.postprocess import remove_small_zones
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x2"])
 @pytest.mark.parametrize("exclude_nodes", [False, True])
-def test_predict_folder_matches_oracle(tmp_path, oracle_model, sd_np, built_lib, exclude_nodes):
+def test_predict_folder_matches_oracle(tmp_path, oracle_model, sd_np, built_lib, exclude_nodes, precision):
+    """configs[4]: trained-like weights loaded from a local .pt, --exclude_nodes, label PNGs and CSV rows against the
+    oracle on eight held frames, in both f32-grade modes under the same allowance."""
     from oracle.fcn_resnet50_oracle import predict_labels
     root = str(tmp_path)
     layout = [("epinette_gelee", "a01.bmp", 30, 256, 256), ("epinette_gelee", "a02.png", 31, 200, 256),
@@ -34,7 +37,7 @@ def test_predict_folder_matches_oracle(tmp_path, oracle_model, sd_np, built_lib,
     ckpt = os.path.join(root, "best_model.pt")
     torch.save({k: torch.from_numpy(v) for k, v in sd_np.items()}, ckpt)     # predict.py:57 loads a local file
 
-    drv.predict_folder(root, ckpt, precision="fp32", exclude_nodes=exclude_nodes, device_index=0)
+    drv.predict_folder(root, ckpt, precision=precision, exclude_nodes=exclude_nodes, device_index=0)
 
     rows = list(csv.reader(open(os.path.join(root, "results", "final_stats.csv")), delimiter="\t"))
     assert rows[0] == drv.CSV_HEADER and len(rows) == 1 + len(layout)
