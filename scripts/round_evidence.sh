@@ -21,7 +21,7 @@ timeout -k 10 200 python scripts/time_folder.py 1000 f16x2,fp32 ragged > $out/ti
 grep -E "run 1" $out/time_folder_ragged.log
 timeout -k 10 200 python scripts/host_ceiling.py 8 16 125 290 2 > $out/host_ceiling_f16x2.log 2>&1 || { tail -5 $out/host_ceiling_f16x2.log; exit 1; }
 timeout -k 10 200 python scripts/host_ceiling.py 8 16 125 840 8 > $out/host_ceiling_bf16.log 2>&1 || { tail -5 $out/host_ceiling_bf16.log; exit 1; }
-tail -3 $out/host_ceiling_f16x2.log $out/host_ceiling_bf16.log
+tail -n 3 $out/host_ceiling_f16x2.log; tail -n 3 $out/host_ceiling_bf16.log
 python3 - <<PY
 import json
 d=json.load(open("$out/bench_default.json"))
