@@ -79,6 +79,10 @@ def parse(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (one-GPU box), implies a gloo process group")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default per-layer tile choice")
+    ap.add_argument("--tune-objective", choices=["auto", "latency", "throughput"], default="auto",
+                    help="what nbc_autotune minimises: a launch's time alone, or time x share of the chip it occupies "
+                         "(auto: throughput when several forwards are in flight)")
+    ap.add_argument("--tune-reps", type=int, default=3, help="timed launches per tile and layer in nbc_autotune")
     ap.add_argument("--dump-ops", default=None, help="write the headline run's per-launch records (JSON) to this file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -246,9 +250,9 @@ def main():
         if args.tiles_file:
             installed = json.load(open(args.tiles_file))
         tune = not args.no_autotune and args.conv_tile < 0 and installed is None
-        objective = "throughput" if nstreams > 1 else "latency"
+        objective = ("throughput" if nstreams > 1 else "latency") if args.tune_objective == "auto" else args.tune_objective
         if tune:
-            tiles = model.autotune(batches[0], objective=objective)   # setup: per-layer tile shape by measurement
+            tiles = model.autotune(batches[0], reps=args.tune_reps, objective=objective)   # setup: per-layer tile shape by measurement
         elif installed is not None:
             tiles = installed[key]
             model.set_plan_tiles(tiles)
@@ -259,7 +263,7 @@ def main():
             m2.reserve(batch, H, W)
             m2.set_conv_tile(args.conv_tile)
             if tune:
-                m2.autotune(batches[0], objective=objective)
+                m2.autotune(batches[0], reps=args.tune_reps, objective=objective)
             elif installed is not None:
                 m2.set_plan_tiles(tiles)
             models.append(m2)

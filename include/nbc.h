@@ -238,6 +238,13 @@ int nbc_default_conv_tile(int M, int Cout, int K, int precision);
  * e.g. one measured in an earlier process: NBC_ERR_INVALID when the count or a tile does not fit. */
 int nbc_set_plan_tiles(nbc_ctx* ctx, const int32_t* tiles, int n);
 
+/* 1 when a forward of this context since the last reset produced a logit that is NaN or infinite, else 0 (negative:
+ * error).  Sticky, raised by classifier.4's launch at no measurable cost.  NaN / inf in the input or the weights do
+ * that in every mode, like in the reference; in NBC_PREC_F16X2 so does an activation beyond f16's range (+-65504), which
+ * that mode cannot represent: a caller that runs unknown weights in f16x2 checks this after its last forward and falls
+ * back to NBC_PREC_FP32 when it is raised (the folder driver does).  Synchronises the device. */
+int nbc_nonfinite_seen(nbc_ctx* ctx, int reset);
+
 /* ---- debugging / measurement ----------------------------------------------------------- */
 /* Copy the activation written by conv unit `name` during the last forward to `dst_host` as
  * float32 NCHW.  `capacity` is in elements.  Only valid when keep-activations is on. */

@@ -696,7 +696,7 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? 3 : 
 #ifdef NBC_STAMPS
   if (p.stamps && lane == 0) { p.stamps[(size_t)blockIdx.x * 64 + 16 + wave] = st_vm; p.stamps[(size_t)blockIdx.x * 64 + 32 + wave] = st_bar; }
 #endif
-  prefetch_identity();
+  if (computes) prefetch_identity();                 // (loader waves own no output rows: their row / channel indices lie outside the tile)
   if constexpr (F32) step32(T - 1, (T - 1) % S, false, false, 0, false, 0, 0);
   else if (computes) compute(T - 1, (T - 1) % S, false, 0, 0);
   }
@@ -968,8 +968,9 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 bool conv_tile_ok(int precision, int tile, int Co) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
   if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
-  if (precision == 2 && !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || tile == 10 || tile >= 13)) return false;
-  if (precision != 2 && tile >= 14) return false;                  // loader-wave tiles: f16x2 only
+  if (precision == 2 && !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || tile == 10 || tile == 13 || tile == 14)) return false;
+  if (precision != 2 && tile == 14) return false;                  // the loader-wave tile is f16x2's (in bf16 a 256x128 tile
+                                                                   // with loader waves ties the one without: section 6.4)
   return Co % kTileCols[tile] == 0;
 }
 

@@ -85,6 +85,7 @@ struct nbc_ctx {
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
   void* scratch256 = nullptr;               // 256 bytes of device scratch (min/max of the preprocessor resize)
+  unsigned* nonfinite = nullptr;            // one device word: bit 0 = a forward produced a NaN / infinite logit (sticky)
   void* zones_ws = nullptr;                 // remove_small_zones workspace: bg bytes, parent ints, size ints
   size_t zones_px = 0;                      // pixels it is sized for
 };
@@ -356,6 +357,7 @@ int nbc_destroy(nbc_ctx* c) {
   if (c->lowres) (void)hipFree(c->lowres);
   if (c->zones_ws) (void)hipFree(c->zones_ws);
   if (c->scratch256) (void)hipFree(c->scratch256);
+  if (c->nonfinite) (void)hipFree(c->nonfinite);
   if (c->owned_weights) (void)hipFree(c->owned_weights);
   for (auto& set : c->prof_sets) for (hipEvent_t ev : set) (void)hipEventDestroy(ev);
   delete c;
@@ -484,6 +486,16 @@ int nbc_set_sub_batch(nbc_ctx* c, const char* first_op, int images) {
   return NBC_OK;                                     // the next nbc_forward / nbc_reserve plans accordingly
 }
 
+int nbc_nonfinite_seen(nbc_ctx* c, int reset) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  if (!c->nonfinite) return 0;                       // no forward yet
+  NBC_HIP(hipSetDevice(c->device));
+  unsigned v = 0;
+  NBC_HIP(hipMemcpy(&v, c->nonfinite, sizeof(v), hipMemcpyDeviceToHost));      // waits for the device: every forward has finished
+  if (reset && v) NBC_HIP(hipMemset(c->nonfinite, 0, sizeof(v)));
+  return v ? 1 : 0;
+}
+
 int nbc_set_profiling(nbc_ctx* c, int on) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
   c->profiling = on != 0;
@@ -521,6 +533,10 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const Plan& P = c->plan;
   const int prec = c->precision;
+  if (!c->nonfinite) {
+    NBC_HIP(hipMalloc((void**)&c->nonfinite, 256));
+    NBC_HIP(hipMemset(c->nonfinite, 0, 256));
+  }
 
   const size_t nops = P.ops.size();
   // launch list: (op, first image, images).  Without a sub-batched tail every op runs once on the whole batch;
@@ -587,7 +603,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         unsigned long long* cz = counts_dev && 3 * N <= 256 ? reinterpret_cast<unsigned long long*>(counts_dev) + 3 * img0 : nullptr;
         e = launch_head1x1(c->bufs[o.in_buf], reinterpret_cast<const float*>(c->weights + pc.w_off),
                            reinterpret_cast<const float*>(c->weights + pc.shift_off),
-                           lowres + (size_t)img0 * kNumClasses * o.Ho * o.Wo, nb, o.Ho * o.Wo, prec, cz, s);
+                           lowres + (size_t)img0 * kNumClasses * o.Ho * o.Wo, nb, o.Ho * o.Wo, prec, cz, c->nonfinite, s);
         break;
       }
       case OP_UPSAMPLE:

@@ -52,8 +52,9 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int N, int Hi, int Wi, in
 // classifier.4: 1x1 conv 512 -> 3 with bias; f32 weights [3][512]; output f32 NCHW [N,3,h,w].
 // counts_zero (nullable, 3*N <= 256 counters): cleared by this launch for the upsample/argmax launch
 // that follows it, which accumulates the per-class pixel counts there (saves a memset node).
+// nonfinite (nullable): one device word that gets bit 0 set when a logit is NaN or infinite.
 hipError_t launch_head1x1(const void* x, const float* w, const float* bias, float* y, int N, int hw,
-                          int precision, unsigned long long* counts_zero, hipStream_t s);
+                          int precision, unsigned long long* counts_zero, unsigned* nonfinite, hipStream_t s);
 // Bicubic (A=-0.75, align_corners=False) upsample of f32 NCHW [N,3,h,w] to HxW, fused with the
 // per-pixel argmax, the optional 2->1 remap and the per-class pixel counts.
 hipError_t launch_upsample_argmax(const float* lowres, int N, int h, int w, int H, int W,

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ y, int M, int hw,
-                                                      unsigned long long* __restrict__ counts_zero, int ncounts) {
+                                                      unsigned long long* __restrict__ counts_zero, int ncounts,
+                                                      unsigned* __restrict__ nonfinite) {
   constexpr int CIN = 512;
   constexpr int PIX_PER_WAVE = 8;
   const int lane = threadIdx.x & 63;
@@ -213,9 +214,13 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const void* __restrict__ x
     if (lane == 0 && m < M) {
       const int img = m / hw, pix = m - img * hw;
       float* yp = y + (size_t)img * 3 * hw + pix;
-      yp[0] = s[0] + b0;
-      yp[(size_t)hw] = s[1] + b1;
-      yp[2 * (size_t)hw] = s[2] + b2;
+      const float l0 = s[0] + b0, l1 = s[1] + b1, l2 = s[2] + b2;
+      yp[0] = l0;
+      yp[(size_t)hw] = l1;
+      yp[2 * (size_t)hw] = l2;
+      // a logit that is not finite (NaN / inf in the input or the weights; in f16x2 mode an activation beyond f16's
+      // range) raises the context's sticky flag: nbc_nonfinite_seen
+      if (nonfinite && !(__builtin_isfinite(l0) && __builtin_isfinite(l1) && __builtin_isfinite(l2))) atomicOr(nonfinite, 1u);
     }
   }
 }
@@ -607,13 +612,13 @@ hipError_t launch_maxpool3x3s2(const void* x, void* y, int N, int Hi, int Wi, in
 }
 
 hipError_t launch_head1x1(const void* x, const float* w, const float* bias, float* y, int N, int hw,
-                          int precision, unsigned long long* counts_zero, hipStream_t s) {
+                          int precision, unsigned long long* counts_zero, unsigned* nonfinite, hipStream_t s) {
   if (3 * N > 256) counts_zero = nullptr;      // the caller then clears the counters itself
   const int M = N * hw;
   const int blocks = (M + 31) / 32;           // 4 waves x 8 pixels
-  if (precision == 0) hipLaunchKernelGGL(head1x1_kernel<0>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
-  else if (precision == 2) hipLaunchKernelGGL(head1x1_kernel<2>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
-  else hipLaunchKernelGGL(head1x1_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N);
+  if (precision == 0) hipLaunchKernelGGL(head1x1_kernel<0>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N, nonfinite);
+  else if (precision == 2) hipLaunchKernelGGL(head1x1_kernel<2>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N, nonfinite);
+  else hipLaunchKernelGGL(head1x1_kernel<1>, dim3(blocks), dim3(256), 0, s, x, w, bias, y, M, hw, counts_zero, 3 * N, nonfinite);
   return hipGetLastError();
 }
 

@@ -300,6 +300,14 @@ class FCNResNet50:
                             k=int(rec.kh), cout=int(rec.cout), launches=int(rec.launches)))
         return out
 
+    def nonfinite_seen(self, reset: bool = True) -> bool:
+        """True when a forward since the last reset produced a NaN / infinite logit (nbc_nonfinite_seen; synchronises).
+        In "f16x2" mode that also means an activation left f16's range: rerun such weights in "fp32"."""
+        rc = self._lib.nbc_nonfinite_seen(self._require_ctx(), int(reset))
+        if rc < 0:
+            _lib.check(rc, "nbc_nonfinite_seen")
+        return rc == 1
+
     def set_sub_batch(self, first_op=None, images: int = 0):
         """Run everything from conv unit `first_op` (the first convolution of a bottleneck, or "classifier.0") to
         classifier.4 depth-first on `images` images at a time (nbc_set_sub_batch); None / 0 = whole-batch plan."""

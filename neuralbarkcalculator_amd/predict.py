@@ -583,6 +583,11 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         sys.setswitchinterval(switch)
     torch.cuda.synchronize()
     t_done = time.perf_counter()
+    if precision == "f16x2" and any(m.nonfinite_seen() for m in models):
+        # f16x2 keeps every value as two f16 pieces: an activation beyond +-65504 cannot be represented and turns into NaN
+        # (never into a silently wrong number).  Unknown weights that do this belong in the f32 MFMA mode.
+        raise RuntimeError("a forward produced non-finite logits in f16x2 mode (an activation beyond f16's range, or NaN/inf in "
+                           "the weights): the label PNGs of this run are not valid; rerun with --precision fp32")
 
     if os.environ.get("NBC_FOLDER_PROFILE"):
         print("rank %d stage seconds (pool stages summed over %d threads): %s; loop wall %.2f s" %

@@ -582,3 +582,24 @@ def test_bcast_weights_non_root_branch_with_a_stub(built_lib, tmp_path):
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stderr[-3000:]
     assert "bcast stub driver OK" in r.stdout
+
+
+def test_f16x2_out_of_range_activations_raise_the_flag(built_lib, sd_np):
+    """NBC_PREC_F16X2 cannot hold a value beyond +-65504: such an activation becomes NaN (never a wrong finite number),
+    the logits behind it are NaN, and nbc_nonfinite_seen says so; the f32 MFMA mode runs the same weights fine, and a
+    normal network never raises the flag."""
+    x = frames([76], 96, 128).to(DEV)
+    big = dict(sd_np)
+    big["backbone.bn1.weight"] = sd_np["backbone.bn1.weight"] * np.float32(3e4)      # stem outputs in the 1e5 range
+    m16 = FCNResNet50("f16x2").load_state_dict(big).to(DEV)
+    m32 = FCNResNet50("fp32").load_state_dict(big).to(DEV)
+    assert not m16.nonfinite_seen() and not m32.nonfinite_seen()                      # nothing run yet
+    low32 = m32.lowres_logits(x)
+    low16 = m16.lowres_logits(x)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(low32).all()) and not m32.nonfinite_seen()
+    assert bool(torch.isnan(low16).any()) and not bool(torch.isinf(low16).any())
+    assert m16.nonfinite_seen(reset=False) and m16.nonfinite_seen() and not m16.nonfinite_seen()   # sticky until reset
+    ok = FCNResNet50("f16x2").load_state_dict(sd_np).to(DEV)
+    ok.predict_labels(x)
+    assert not ok.nonfinite_seen()
