@@ -3,6 +3,9 @@
 #include "nbc_net.hpp"
 
 #include <cmath>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -181,6 +184,50 @@ void split_f16x2(float x, uint16_t* h0, uint16_t* h1) {
   *h1 = f32_to_f16((x - f16_to_f32(*h0)) * 2048.0f);                // the difference is exact, the scaling a power of two
 }
 
+// In-place split of packed f32 weight rows into the f16x2 group layout: every `group` consecutive floats (32 = one
+// 128-byte K-step row segment; 4 = the stem's 16-byte tap) become [h0 x group][h1 x group].  33 M weights: the x86 F16C
+// conversion (round to nearest even, subnormals: IEEE, like split_f16x2) where the host has it, else the portable one.
+#if defined(__x86_64__)
+__attribute__((target("avx,f16c"))) static void split_groups_f16c(float* data, size_t nfloats, int group) {
+  alignas(32) uint16_t h0[32], h1[32];
+  const __m256 scale = _mm256_set1_ps(2048.0f);
+  for (size_t g = 0; g + group <= nfloats; g += group) {
+    float* x = data + g;
+    if (group == 32) {
+      for (int i = 0; i < 32; i += 8) {
+        const __m256 v = _mm256_loadu_ps(x + i);
+        const __m128i a = _mm256_cvtps_ph(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        const __m256 r = _mm256_mul_ps(_mm256_sub_ps(v, _mm256_cvtph_ps(a)), scale);
+        _mm_store_si128(reinterpret_cast<__m128i*>(h0 + i), a);
+        _mm_store_si128(reinterpret_cast<__m128i*>(h1 + i), _mm256_cvtps_ph(r, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+      }
+      std::memcpy(x, h0, 64);
+      std::memcpy(reinterpret_cast<unsigned char*>(x) + 64, h1, 64);
+    } else {                                           // group 4
+      const __m128 v = _mm_loadu_ps(x);
+      const __m128i a = _mm_cvtps_ph(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+      const __m128 r = _mm_mul_ps(_mm_sub_ps(v, _mm_cvtph_ps(a)), _mm_set1_ps(2048.0f));
+      const __m128i b = _mm_cvtps_ph(r, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+      const uint64_t lo = (uint64_t)_mm_cvtsi128_si64(a), hi = (uint64_t)_mm_cvtsi128_si64(b);
+      std::memcpy(x, &lo, 8);
+      std::memcpy(reinterpret_cast<unsigned char*>(x) + 8, &hi, 8);
+    }
+  }
+}
+#endif
+
+static void split_groups(float* data, size_t nfloats, int group) {
+#if defined(__x86_64__)
+  if (__builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx")) { split_groups_f16c(data, nfloats, group); return; }
+#endif
+  uint16_t h0[32], h1[32];
+  for (size_t g = 0; g + group <= nfloats; g += group) {
+    for (int i = 0; i < group; ++i) split_f16x2(data[g + i], &h0[i], &h1[i]);
+    std::memcpy(data + g, h0, (size_t)group * 2);
+    std::memcpy(reinterpret_cast<unsigned char*>(data + g) + group * 2, h1, (size_t)group * 2);
+  }
+}
+
 thread_local std::string g_last_error;
 
 int set_error(int code, const std::string& msg) {
@@ -297,18 +344,12 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
             const float v = w[(((size_t)o * c.cin + ci) * c.k + kh) * c.k + kw];
             const size_t kidx = p.stem ? (size_t)(kh * 8 + kw) * p.cin_pad + ci      // stem: eight slots per kernel row
                                        : (size_t)(kh * c.k + kw) * p.cin_pad + ci;
-            if (precision == NBC_PREC_F16X2) {
-              // element kidx of the row in its f32-sized slot: 32-element groups of [h0 x 32][h1 x 32]; the stem's
-              // 16-byte tap is [h0 x 4][h1 x 4]
-              uint16_t h0, h1;
-              split_f16x2(v, &h0, &h1);
-              uint16_t* r16 = reinterpret_cast<uint16_t*>(row);
-              if (p.stem) { r16[(kidx / 4) * 8 + kidx % 4] = h0; r16[(kidx / 4) * 8 + 4 + kidx % 4] = h1; }
-              else { r16[(kidx / 32) * 64 + kidx % 32] = h0; r16[(kidx / 32) * 64 + 32 + kidx % 32] = h1; }
-            } else if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;
+            if (eb == 4) reinterpret_cast<float*>(row)[kidx] = v;        // f16x2: split in place below
             else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
           }
     }
+    if (precision == NBC_PREC_F16X2)   // element e of a row in its f32-sized slot -> 32-element groups [h0 x 32][h1 x 32] (stem: taps of 4)
+      split_groups(reinterpret_cast<float*>(base + p.w_off), (size_t)c.cout * row_bytes / 4, p.stem ? 4 : 32);
     // eval-mode BatchNorm as ATen applies it: alpha = gamma * invstd, beta = bias - mean * alpha
     const float* g = static_cast<const float*>(given[c.bn + ".weight"]->data);
     const float* b = static_cast<const float*>(given[c.bn + ".bias"]->data);
