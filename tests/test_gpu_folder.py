@@ -233,7 +233,7 @@ def test_predict_cli_matches_the_library_call(tmp_path, sd_np, built_lib):
             assert p.returncode == 0, p.stderr[-3000:]
             assert "predicted 3 images" in p.stdout
         else:
-            drv.predict_folder(root, ckpt, exclude_nodes=True, device_index=0, streams=2)
+            drv.predict_folder(root, ckpt, precision="f16x2", exclude_nodes=True, device_index=0, streams=2)    # the CLI's default mode
         labs = {}
         for wood in ("sapin", "epinette_gelee"):
             d = os.path.join(root, "results", "outputs", wood)
@@ -291,3 +291,30 @@ def test_mixed_folder_is_independent_of_batching_and_streams(tmp_path, sd_np, bu
     assert len(seen) == 1
     heights = sorted(np.asarray(Image.open(os.path.join(root, "processed", "samples", "epinette_gelee", "t%d.png" % i))).shape[0] for i in range(5))
     assert heights == [554, 584, 614, 644, 674]          # trim_black cut the bands
+
+
+def test_cli_falls_back_to_fp32_when_f16x2_overflows(tmp_path, sd_np, built_lib):
+    """--precision auto (the default): weights that drive an activation beyond f16's range make the f16x2 run raise
+    NonFiniteLogits (the library's sticky flag), and the CLI runs the folder again on the f32 MFMA: same files as a plain
+    fp32 library call; the library call in f16x2 raises."""
+    import subprocess
+    import sys
+    big = dict(sd_np)
+    big["backbone.bn1.weight"] = sd_np["backbone.bn1.weight"] * np.float32(3e4)
+    layout = [("sapin", "a.bmp", 11, 88, 120), ("epinette_gelee", "c.png", 13, 64, 200)]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root_cli, root_call = str(tmp_path / "cli"), str(tmp_path / "call")
+    ckpt, _ = _make_folder(root_cli, big, layout)
+    ckpt2, _ = _make_folder(root_call, big, layout)
+    p = subprocess.run([sys.executable, "-m", "neuralbarkcalculator_amd.predict", root_cli, "--model_path", ckpt],
+                       cwd=repo, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "running the folder again on the f32 MFMA" in p.stdout and "predicted 2 images" in p.stdout
+    with pytest.raises(drv.NonFiniteLogits):
+        drv.predict_folder(root_call, ckpt2, precision="f16x2", device_index=0)
+    drv.predict_folder(root_call, ckpt2, precision="fp32", device_index=0)
+    assert open(os.path.join(root_cli, "results", "final_stats.csv")).read() == open(os.path.join(root_call, "results", "final_stats.csv")).read()
+    for wood, name in (("sapin", "a.png"), ("epinette_gelee", "c.png")):
+        a = np.asarray(Image.open(os.path.join(root_cli, "results", "outputs", wood, name)))
+        b = np.asarray(Image.open(os.path.join(root_call, "results", "outputs", wood, name)))
+        assert np.array_equal(a, b)
