@@ -95,6 +95,9 @@ def parse(argv=None):
     ap.add_argument("--sub-batch", default="auto",
                     help="sub-batched tail of a leg with batch > 1: 'auto' (the library's default), 'off', or "
                          "'<first op>:<images>', e.g. backbone.layer4.0.conv1:2")
+    ap.add_argument("--fusion", type=int, default=-1,
+                    help="f16x2: bottlenecks run as one fused launch, bits 0..4 = layer1.1, layer1.2, layer2.1, layer2.2, layer2.3 "
+                         "(-1 = the library's default, 0 = none)")
     ap.add_argument("--no-op-events", action="store_true", help="no instrumented region (no roofline object)")
     ap.add_argument("--save-tiles", default=None, help="write the measured per-layer tile choices (JSON) to this file")
     ap.add_argument("--tiles-file", default=None,
@@ -242,6 +245,7 @@ def main():
                 name, n = args.sub_batch.rsplit(":", 1)
                 m.set_sub_batch(name, int(n))
         apply_sub_batch(model)
+        model.set_fusion(args.fusion)
         model.reserve(batch, H, W)
         model.set_conv_tile(args.conv_tile)
         tiles = None
@@ -260,6 +264,7 @@ def main():
         for _ in range(nstreams - 1):
             m2 = model.clone_shared()
             apply_sub_batch(m2)
+            m2.set_fusion(args.fusion)
             m2.reserve(batch, H, W)
             m2.set_conv_tile(args.conv_tile)
             if tune:

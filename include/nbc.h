@@ -216,6 +216,13 @@ int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
  * NULL or images < 1 turns it off (the default).  Calls with N <= images, and keep-activations mode, run whole-batch. */
 int nbc_set_sub_batch(nbc_ctx* ctx, const char* first_op, int images);
 
+/* Whole-bottleneck fusion (NBC_PREC_F16X2): the five bottlenecks without downsample of layer1 and layer2 (layer1.1,
+ * layer1.2, layer2.1, layer2.2, layer2.3 = bits 0..4 of `mask`) run as ONE launch each instead of three convolutions
+ * (x read once, t1 and t2 never leave LDS), bit-identical to them.  mask -1 = the library's default, 0 = off.
+ * stop_after 1 / 2 is for tests: the fused launch ends behind conv1 / conv2 and the unfused convolutions finish the block.
+ * Other precisions and keep-activations plans always run the three convolutions. */
+int nbc_set_fusion(nbc_ctx* ctx, int mask, int stop_after);
+
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real
  * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the
  * current (N,H,W) plan (`reps` launches each, HIP events) and keeps the fastest.  Results do not

@@ -58,6 +58,7 @@ SIGNATURES = {
     "nbc_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "nbc_set_sub_batch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nbc_nonfinite_seen": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbc_set_fusion": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "nbc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p]),

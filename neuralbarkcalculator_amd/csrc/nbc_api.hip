@@ -28,7 +28,7 @@ namespace {
       return set_error(NBC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
   } while (0)
 
-enum OpKind { OP_INGEST, OP_CONV, OP_MAXPOOL, OP_HEAD1X1, OP_UPSAMPLE };
+enum OpKind { OP_INGEST, OP_CONV, OP_MAXPOOL, OP_HEAD1X1, OP_UPSAMPLE, OP_BOTTLENECK };
 
 struct Op {
   OpKind kind;
@@ -39,6 +39,7 @@ struct Op {
   double flops, bytes;
   int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
   bool in_full, res_full;   // sub-batched tail: the input / identity buffer holds the whole batch (the image offset applies)
+  int stop_after;           // OP_BOTTLENECK: 0 = the whole bottleneck (unit = its conv1); 1 / 2 (tests): t1 / t2 into out_buf
 };
 
 struct Plan {
@@ -53,6 +54,7 @@ struct Plan {
   int sub_from = -1, sub_n = 0;
   std::string sub_first;               // the request the plan was built for (part of its identity)
   int sub_req = 0;
+  int fuse_mask = 0, fuse_stop = 0;    // likewise: nbc_set_fusion
 };
 
 }  // namespace
@@ -74,6 +76,8 @@ struct nbc_ctx {
   int conv_tile = -1;                       // tile override, -1 = per-layer choice
   std::string sub_first;                    // sub-batched tail: its first op ("" = none) ...
   int sub_n = 0;                            // ... and images per sub-batch (nbc_set_sub_batch)
+  int fuse_mask = -1;                       // f16x2: which of the five fusable bottlenecks run as one launch (nbc_set_fusion); -1 = default
+  int fuse_stop = 0;                        // tests: the fused launch stops behind conv1 / conv2, the unfused rest follows
   bool keep = false;
   bool profiling = false;
   // profiling: one event set (nops+1 events) per profiled forward, read back lazily so that the
@@ -93,12 +97,14 @@ struct nbc_ctx {
 namespace {
 
 constexpr size_t kPlanCacheEntries = 64;
+constexpr int kDefaultFuseMask = 0x1f;      // all five (layer1.1, layer1.2, layer2.1, layer2.2, layer2.3)
 
 bool same_shape(const Plan& p, int N, int H, int W, int precision, bool keep) {
   return p.N == N && p.H == H && p.W == W && p.precision == precision && p.keep == keep;
 }
 bool same_plan(const Plan& p, const nbc_ctx* c, int N, int H, int W) {
-  return same_shape(p, N, H, W, c->precision, c->keep) && p.sub_first == c->sub_first && p.sub_req == c->sub_n;
+  return same_shape(p, N, H, W, c->precision, c->keep) && p.sub_first == c->sub_first && p.sub_req == c->sub_n &&
+         p.fuse_mask == c->fuse_mask && p.fuse_stop == c->fuse_stop;
 }
 
 // Park the current plan (folders of height-trimmed images alternate between a few shapes: each keeps
@@ -107,7 +113,8 @@ void stash_plan(nbc_ctx* c) {
   Plan& cur = c->plan;
   if (cur.N == 0) return;
   for (Plan& p : c->plan_cache)
-    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep) && p.sub_first == cur.sub_first && p.sub_req == cur.sub_req) {
+    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep) && p.sub_first == cur.sub_first && p.sub_req == cur.sub_req &&
+        p.fuse_mask == cur.fuse_mask && p.fuse_stop == cur.fuse_stop) {
       p = cur; cur = Plan(); return;
     }
   if (c->plan_cache.size() >= kPlanCacheEntries) c->plan_cache.erase(c->plan_cache.begin());
@@ -121,6 +128,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
   Plan P;
   P.N = N; P.H = H; P.W = W; P.precision = c->precision; P.keep = c->keep;
   P.sub_first = c->sub_first; P.sub_req = c->sub_n;
+  P.fuse_mask = c->fuse_mask; P.fuse_stop = c->fuse_stop;
   // the tail runs in sub-batches when one is asked for, it is smaller than the batch, and every op keeps its own
   // buffer for the whole batch is not asked for (layer-by-layer tests read whole-batch activations)
   const bool want_sub = !c->sub_first.empty() && c->sub_n >= 1 && c->sub_n < N && !c->keep;
@@ -197,8 +205,52 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     ui = 1;
   }
   // bottlenecks
+  int fusable = 0;                     // running index of the bottlenecks the fused kernel covers (bits of fuse_mask)
   while (ui < units.size() && units[ui].block_first) {
     int h1, w1, h2, w2, h3, w3;
+    // f16x2: a bottleneck without downsample, stride and dilation 1, 64 or 128 mid channels (layer1.1-2, layer2.1-3)
+    // runs as ONE launch (bottleneck_fused.hip), bit-identical to its three convolutions; keep-activations plans keep
+    // the three (the layer-by-layer tests read conv1 / conv2)
+    const bool shape_ok = units[ui + 2].residual && units[ui + 1].stride == 1 && units[ui + 1].dil == 1 &&
+                          (units[ui].cout == 64 || units[ui].cout == 128) && units[ui].cin == 4 * units[ui].cout;
+    if (shape_ok) {
+      const int bit = fusable++;
+      const int mask = c->fuse_mask < 0 ? kDefaultFuseMask : c->fuse_mask;
+      if (c->precision == NBC_PREC_F16X2 && !P.keep && ((mask >> bit) & 1)) {
+        const int cm = units[ui].cout, c4 = 4 * cm;
+        if (want_sub && !in_tail && c->sub_first == units[ui].name) {
+          in_tail = true; boundary = cur; NB = c->sub_n;
+          P.sub_from = (int)P.ops.size(); P.sub_n = NB;
+        }
+        const int stop = c->fuse_stop;
+        Op o{};
+        o.kind = OP_BOTTLENECK; o.unit = (int)ui; o.in_buf = cur; o.res_buf = -1; o.stop_after = stop;
+        o.in_full = in_tail && cur == boundary;
+        o.Hi = curH; o.Wi = curW; o.Ci = c4; o.Ho = curH; o.Wo = curW; o.Co = stop ? cm : c4;
+        const std::string block = units[ui].name.substr(0, units[ui].name.rfind('.'));
+        o.name = block + (stop == 1 ? ".fused_conv1" : stop == 2 ? ".fused_conv1_conv2" : ".fused");
+        o.out_buf = acquire((size_t)NB * curH * curW * o.Co * eb);
+        const double M = (double)N * curH * curW;
+        o.flops = 2.0 * M * ((double)cm * c4 + (stop != 1 ? 9.0 * cm * cm : 0.0) + (stop == 0 ? (double)c4 * cm : 0.0));
+        o.bytes = (M * c4 + M * o.Co + (double)cm * c4 + (stop != 1 ? 9.0 * cm * cm : 0.0) + (stop == 0 ? (double)c4 * cm : 0.0)) * eb;
+        P.ops.push_back(o);
+        int out = o.out_buf;
+        if (stop == 1) {                               // tests: the unfused conv2 and conv3 follow the fused conv1
+          const int t2 = add_conv((int)ui + 1, out, curH, curW, cm, -1, &h2, &w2);
+          release(out);
+          out = add_conv((int)ui + 2, t2, h2, w2, cm, cur, &h3, &w3);
+          release(t2);
+        } else if (stop == 2) {
+          const int t2 = out;
+          out = add_conv((int)ui + 2, t2, curH, curW, cm, cur, &h3, &w3);
+          release(t2);
+        }
+        release(cur);
+        cur = out;
+        ui += 3;
+        continue;
+      }
+    }
     const int t1 = add_conv((int)ui, cur, curH, curW, curC, -1, &h1, &w1);
     const int t2 = add_conv((int)ui + 1, t1, h1, w1, units[ui].cout, -1, &h2, &w2);
     release(t1);
@@ -324,6 +376,7 @@ const char* kernel_name(OpKind k) {
     case OP_CONV: return "conv_dma";
     case OP_MAXPOOL: return "maxpool";
     case OP_HEAD1X1: return "head1x1";
+    case OP_BOTTLENECK: return "bottleneck_x2";
     default: return "upsample_argmax";
   }
 }
@@ -486,6 +539,14 @@ int nbc_set_sub_batch(nbc_ctx* c, const char* first_op, int images) {
   return NBC_OK;                                     // the next nbc_forward / nbc_reserve plans accordingly
 }
 
+int nbc_set_fusion(nbc_ctx* c, int mask, int stop_after) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  if (mask < -1 || mask > 0x1f || stop_after < 0 || stop_after > 2) return set_error(NBC_ERR_INVALID, "nbc_set_fusion: mask -1 .. 31, stop_after 0 .. 2");
+  c->fuse_mask = mask;
+  c->fuse_stop = stop_after;
+  return NBC_OK;                                     // the next nbc_forward / nbc_reserve plans accordingly
+}
+
 int nbc_nonfinite_seen(nbc_ctx* c, int reset) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
   if (!c->nonfinite) return 0;                       // no forward yet
@@ -596,6 +657,28 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
       case OP_MAXPOOL:
         e = launch_maxpool3x3s2(c->bufs[o.in_buf], c->bufs[o.out_buf], N, o.Hi, o.Wi, o.Ci, o.Ho, o.Wo, prec, s);
         break;
+      case OP_BOTTLENECK: {
+        const auto& units = conv_units();
+        const PackedConv &p1 = c->layout.convs[o.unit], &p2 = c->layout.convs[o.unit + 1], &p3 = c->layout.convs[o.unit + 2];
+        const int cm = units[o.unit].cout;
+        const size_t xb = (size_t)nb * o.Hi * o.Wi * o.Ci * 4;
+        if (xb >= 0x80000000ull) return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
+        BottleneckArgs a{};
+        a.x = static_cast<const unsigned char*>(c->bufs[o.in_buf]) + (o.in_full ? (size_t)img0 * o.Hi * o.Wi * o.Ci * 4 : 0);
+        a.out = o.stop_after ? nullptr : c->bufs[o.out_buf];
+        a.dbg = o.stop_after ? c->bufs[o.out_buf] : nullptr;
+        a.w1 = c->weights + p1.w_off; a.w2 = c->weights + p2.w_off; a.w3 = c->weights + p3.w_off;
+        a.s1 = reinterpret_cast<const float*>(c->weights + p1.scale_off); a.b1 = reinterpret_cast<const float*>(c->weights + p1.shift_off);
+        a.s2 = reinterpret_cast<const float*>(c->weights + p2.scale_off); a.b2 = reinterpret_cast<const float*>(c->weights + p2.shift_off);
+        a.s3 = reinterpret_cast<const float*>(c->weights + p3.scale_off); a.b3 = reinterpret_cast<const float*>(c->weights + p3.shift_off);
+        a.x_bytes = (unsigned)xb;
+        a.w1_bytes = (unsigned)((size_t)cm * p1.ksteps * kKStepBytes);
+        a.w2_bytes = (unsigned)((size_t)cm * p2.ksteps * kKStepBytes);
+        a.w3_bytes = (unsigned)((size_t)4 * cm * p3.ksteps * kKStepBytes);
+        a.N = nb; a.H = o.Hi; a.W = o.Wi; a.stop_after = o.stop_after;
+        e = launch_bottleneck_x2(a, cm, s);
+        break;
+      }
       case OP_HEAD1X1: {
         const PackedConv& pc = c->layout.convs[o.unit];
         if (o.Ci != 512) return set_error(NBC_ERR_STATE, "classifier.4 expects 512 input channels");

@@ -308,6 +308,11 @@ class FCNResNet50:
             _lib.check(rc, "nbc_nonfinite_seen")
         return rc == 1
 
+    def set_fusion(self, mask: int = -1, stop_after: int = 0):
+        """f16x2: which of the five bottlenecks without downsample of layer1 / layer2 run as one fused launch (bits 0..4;
+        -1 = the library's default, 0 = none); stop_after 1 / 2 (tests) ends the fused launch behind conv1 / conv2."""
+        _lib.check(self._lib.nbc_set_fusion(self._require_ctx(), int(mask), int(stop_after)), "nbc_set_fusion")
+
     def set_sub_batch(self, first_op=None, images: int = 0):
         """Run everything from conv unit `first_op` (the first convolution of a bottleneck, or "classifier.0") to
         classifier.4 depth-first on `images` images at a time (nbc_set_sub_batch); None / 0 = whole-batch plan."""
