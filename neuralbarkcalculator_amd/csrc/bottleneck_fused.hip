@@ -64,15 +64,19 @@ struct Geo {
   static constexpr int STG1 = (HR + CM) * 128;          // ring slot of phase 1 (x rows, then w1 rows)
   static constexpr int STG2 = CM * 128;                 // ring slot of phase 2 (w2 rows)
   static constexpr int CHUNK3 = KS3 * NC * 128;         // one chunk of w3: [K-step][NC rows][128 B]
-  static constexpr int R_T = 0;                         // t1 / t2 image
+  // LDS regions.  T: the t1 / t2 image.  B: w3's two chunk buffers.  T and B together: the three slots of phase 1's
+  // ring (the image is written only when that ring is done).  C: w2's ring (S2 slots; started at kernel entry) and,
+  // once phase 2 is over, the per-wave transpose scratch of phase 3.
+  static constexpr int R_T = 0;
   static constexpr int T_BYTES = HR * P * 128;
-  static constexpr int R_B = T_BYTES;                   // rings
+  static constexpr int R_B = T_BYTES;
   static constexpr int B_BYTES = 65536;
-  static constexpr int R_C = R_B + B_BYTES;             // per-wave transpose scratch of phase 3
+  static constexpr int R_C = R_B + B_BYTES;
+  static constexpr int S2 = CM == 64 ? 3 : 2;           // slots of w2's ring
   static constexpr int PITCH3 = CB3 * 16 * 4 + 16;
-  static constexpr int C_BYTES = 8 * 16 * PITCH3;
+  static constexpr int C_BYTES = (8 * 16 * PITCH3 > S2 * STG2) ? 8 * 16 * PITCH3 : S2 * STG2;
   static constexpr int LDS = R_C + C_BYTES;
-  static_assert(2 * STG1 <= B_BYTES && 3 * STG2 <= B_BYTES && 2 * CHUNK3 <= B_BYTES, "rings fit their region");
+  static_assert(3 * STG1 <= T_BYTES + B_BYTES && 2 * CHUNK3 <= B_BYTES && LDS <= 160 * 1024, "regions fit");
   static_assert(RB1 * WR1 * 16 == HR && CB1 * (8 / WR1) * 16 == CM, "phase 1 tiling");
   static_assert(RB2 * WR2 * 16 == PX && CB2 * (8 / WR2) * 16 == CM, "phase 2 tiling");
   static_assert(RB3 * WR3 * 16 == PX && CB3 * (8 / WR3) * 16 == NC, "phase 3 tiling");
@@ -167,6 +171,41 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
   const unsigned pix_bytes = (unsigned)G::C4 * 4u;
   const unsigned img_base = (unsigned)img * (unsigned)p.H * (unsigned)p.W;
 
+  // w2's ring (region C) is loaded by waves 0-3, w3's chunks (region B) by waves 4-7: each wave's vmcnt then counts
+  // one stream of LDS-DMAs at a time.  The first w2 K-steps start here, under phase 1.
+  const rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), 0, p.w2_bytes, 0x00020000);
+  constexpr int L2 = (CM / 8) / 4;                       // w2 pieces per K-step and loading wave: 2 or 4
+  unsigned off2[L2];
+#pragma unroll
+  for (int i = 0; i < L2; ++i) {
+    const int row = 8 * ((wave & 3) + 4 * i) + (lane >> 3);
+    off2[i] = (unsigned)row * (unsigned)(G::KS2 * 128) + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+  auto issue2 = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < L2; ++i)
+      dma16_buf(off2[i], w2rsrc, smem_base + (unsigned)(G::R_C + (t % G::S2) * G::STG2 + ((wave & 3) + 4 * i) * 1024), (unsigned)t * 128u);
+  };
+  if (wave < 4) {
+#pragma unroll
+    for (int t = 0; t < G::S2 - 1; ++t) issue2(t);
+  }
+  const rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, p.w3_bytes, 0x00020000);
+  constexpr int RPK = G::NC / 8;                         // pieces per K-step plane of a w3 chunk (32 pieces per chunk)
+  unsigned off3[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int slot = (wave & 3) + 4 * i;
+    const int ks = slot / RPK, row = 8 * (slot - ks * RPK) + (lane >> 3);
+    off3[i] = (unsigned)row * (unsigned)(G::KS3 * 128) + (unsigned)ks * 128u + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
+  }
+  auto issue3 = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      dma16_buf(off3[i], w3rsrc, smem_base + (unsigned)(G::R_B + (c & 1) * G::CHUNK3 + ((wave & 3) + 4 * i) * 1024),
+                (unsigned)c * (unsigned)(G::NC * G::KS3 * 128));
+  };
+
   // ================= phase 1: t1 = relu(bn1(conv1(x))) on the halo patch =================
   {
     const rsrc_t w1rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, p.w1_bytes, 0x00020000);
@@ -192,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
       for (int i = 0; i < 4; ++i) {
         const int slot = wave + 8 * i;                   // wave-uniform
         if (slot < NS) {
-          const unsigned dst = smem_base + (unsigned)(G::R_B + stage * G::STG1 + slot * 1024);
+          const unsigned dst = smem_base + (unsigned)(stage * G::STG1 + slot * 1024);      // slots span regions T and B
           if (slot < NA) dma16_buf(off[i], xrsrc, dst, (unsigned)t * 128u);
           else dma16_buf(off[i], w1rsrc, dst, (unsigned)t * 128u);
         }
@@ -201,13 +240,18 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
     const int wr = wave % G::WR1, wc = wave / G::WR1;
     Acc<G::RB1, G::CB1> acc;
     acc.clear();
+    const bool four = wave + 24 < NS;                    // this wave issues four pieces per K-step (else three)
     issue(0, 0);
+    issue(1, 1);
     for (int t = 0; t < G::KS1; ++t) {
-      wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                      // slot t % 2 is complete and visible; the other has been read by all
-      if (t + 1 < G::KS1) issue(t + 1, (t + 1) & 1);
+      // own pieces of step t have landed when only step t+1's are outstanding (older LDS-DMAs -- w2's first K-steps --
+      // retire first: vmcnt is in order)
+      if (t + 1 < G::KS1) { if (four) wait_vmcnt<4>(); else wait_vmcnt<3>(); }
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                      // slot t % 3 is complete and visible; slot (t - 1) % 3 has been read by all
+      if (t + 2 < G::KS1) issue(t + 2, (t + 2) % 3);
       if (t > 0 && (t & 7) == 0) acc.flush();
-      const unsigned char* sa = smem + G::R_B + (t & 1) * G::STG1;
+      const unsigned char* sa = smem + (t % 3) * G::STG1;
       const unsigned char* sb = sa + G::HR * 128;
       uint4 p0[G::RB1], p1[G::RB1], w0[G::CB1], w1[G::CB1];
 #pragma unroll
@@ -224,7 +268,9 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
       }
       acc.step(p0, p1, w0, w1);
     }
-    // t1 -> LDS image (the image region is not the ring: no barrier needed before writing it)
+    __syncthreads();                                     // the ring (regions T and B) has been read by all
+    if (wave >= 4) { issue3(0); if (G::NCH > 1) issue3(1); }       // w3's first chunks arrive under phase 2
+    // t1 -> LDS image
 #pragma unroll
     for (int j = 0; j < G::CB1; ++j) {
       const int ch = (wc * G::CB1 + j) * 16 + 4 * q16;
@@ -255,35 +301,21 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
 
   // ================= phase 2: t2 = relu(bn2(conv2(t1))) =================
   {
-    const rsrc_t w2rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), 0, p.w2_bytes, 0x00020000);
-    constexpr int NS = CM / 8;                           // pieces of a ring slot (w2 rows): 8 or 16
-    constexpr int L = (NS + 7) / 8;                      // per wave: 1 or 2
-    unsigned off[L];
-#pragma unroll
-    for (int i = 0; i < L; ++i) {
-      const int row = 8 * (wave + 8 * i) + (lane >> 3);
-      off[i] = (unsigned)row * (unsigned)(G::KS2 * 128) + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-    }
-    auto issue = [&](int t, int stage) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < L; ++i)
-        dma16_buf(off[i], w2rsrc, smem_base + (unsigned)(G::R_B + stage * G::STG2 + (wave + 8 * i) * 1024), (unsigned)t * 128u);
-    };
     const int wr = wave % G::WR2, wc = wave / G::WR2;
     Acc<G::RB2, G::CB2> acc;
     acc.clear();
-    issue(0, 0);
-    issue(1, 1);
     for (int t = 0; t < G::KS2; ++t) {
-      if (t + 1 < G::KS2) wait_vmcnt<L>();               // own pieces of step t have landed (step t+1's may be in flight)
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();                      // slot t % 3 visible; slot (t-1) % 3 has been read by all
-      if (t + 2 < G::KS2) issue(t + 2, (t + 2) % 3);
+      if (wave < 4) {                                    // the loading waves: own pieces of step t have landed
+        if (t + G::S2 - 2 < G::KS2) wait_vmcnt<(G::S2 - 2) * L2>();
+        else wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();                      // slot t % S2 visible; slot (t-1) % S2 has been read by all
+      if (wave < 4 && t + G::S2 - 1 < G::KS2) issue2(t + G::S2 - 1);
       if (t > 0 && (t & 7) == 0) acc.flush();
       const int tap = t / G::P, cb = t - tap * G::P;
       const int kh = tap / 3, kw = tap - kh * 3;
       const unsigned char* sa = smem + G::R_T + cb * (G::HR * 128);
-      const unsigned char* sb = smem + G::R_B + (t % 3) * G::STG2;
+      const unsigned char* sb = smem + G::R_C + (t % G::S2) * G::STG2;
       uint4 p0[G::RB2], p1[G::RB2], w0[G::CB2], w1[G::CB2];
 #pragma unroll
       for (int i = 0; i < G::RB2; ++i) {
@@ -326,24 +358,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
 
   // ================= phase 3: out = relu(bn3(conv3(t2)) + x) =================
   {
-    const rsrc_t w3rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w3), 0, p.w3_bytes, 0x00020000);
-    constexpr int RPK = G::NC / 8;                       // pieces per K-step plane of a chunk
-    unsigned off[4];                                     // 32 pieces per chunk: 4 per wave
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int slot = wave + 8 * i;
-      const int ks = slot / RPK, row = 8 * (slot - ks * RPK) + (lane >> 3);
-      off[i] = (unsigned)row * (unsigned)(G::KS3 * 128) + (unsigned)ks * 128u + (unsigned)((lane & 7) ^ ((row >> 1) & 7)) * 16u;
-    }
-    auto issue = [&](int c) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        dma16_buf(off[i], w3rsrc, smem_base + (unsigned)(G::R_B + (c & 1) * G::CHUNK3 + (wave + 8 * i) * 1024),
-                  (unsigned)c * (unsigned)(G::NC * G::KS3 * 128));
-    };
     const int wr = wave % G::WR3, wc = wave / G::WR3;
-    issue(0);
-    if (G::NCH > 1) issue(1);
     // pixel fragments of t2 do not change from chunk to chunk: read once
     uint4 p0[G::KS3][G::RB3], p1[G::KS3][G::RB3];
 #pragma unroll
@@ -361,9 +376,26 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
     const int o_pix = lane / LPP, o_c8 = lane % LPP;
     unsigned char* scr = smem + G::R_C + wave * (16 * G::PITCH3);
     for (int c = 0; c < G::NCH; ++c) {
-      if (c + 1 < G::NCH) wait_vmcnt<4>();               // own pieces of chunk c have landed (chunk c+1's may be in flight)
-      else wait_vmcnt<0>();
+      if (wave >= 4) {                                   // the loading waves: own pieces of chunk c have landed
+        if (c + 1 < G::NCH) wait_vmcnt<8>();             // (chunk c+1's may be in flight; stores of the last epilogue are
+        else wait_vmcnt<0>();                            //  younger and make this wait longer than needed, never shorter)
+      }
       __builtin_amdgcn_s_barrier();
+      // the identity rows of this chunk are requested now and arrive under the chunk's MFMAs and the first transposes
+      uint4 idp[G::RB3][PASSES][2];
+#pragma unroll
+      for (int i = 0; i < G::RB3; ++i)
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+          const int prow = ps * PPP + o_pix;
+          const int y = y0 + wr * G::RB3 + i, xx = x0 + prow;
+          const int yc = y < p.H ? y : p.H - 1, xc = (prow < 16 && xx < p.W) ? xx : x0;     // a valid address; unused when outside
+          const int ch = c * G::NC + wc * (G::CB3 * 16) + o_c8 * 8;
+          const unsigned char* xp = static_cast<const unsigned char*>(p.x) + (size_t)(img_base + (unsigned)yc * p.W + xc) * pix_bytes +
+                                    (unsigned)(ch >> 5) * 128u + (unsigned)((ch & 31) >> 3) * 16u;
+          idp[i][ps][0] = *reinterpret_cast<const uint4*>(xp);
+          idp[i][ps][1] = *reinterpret_cast<const uint4*>(xp + 64);
+        }
       Acc<G::RB3, G::CB3> acc;
       acc.clear();
       const unsigned char* cb_base = smem + G::R_B + (c & 1) * G::CHUNK3;
@@ -379,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
         acc.step(p0[ks], p1[ks], w0, w1);
       }
       __builtin_amdgcn_s_barrier();                      // every wave has read chunk c: its buffer takes chunk c + 2
-      if (c + 2 < G::NCH) issue(c + 2);
+      if (wave >= 4 && c + 2 < G::NCH) issue3(c + 2);
       // epilogue of the chunk, one 16-pixel row block at a time through the wave's scratch
 #pragma unroll
       for (int i = 0; i < G::RB3; ++i) {
@@ -405,9 +437,8 @@ __global__ __launch_bounds__(512, 2) void bottleneck_x2_kernel(const BottleneckA
             if (y < p.H && xx < p.W) {
               const int ch = c * G::NC + wc * (G::CB3 * 16) + o_c8 * 8;
               const size_t at = (size_t)(img_base + (unsigned)y * p.W + xx) * pix_bytes + (unsigned)(ch >> 5) * 128u + (unsigned)((ch & 31) >> 3) * 16u;
-              const unsigned char* xp = static_cast<const unsigned char*>(p.x) + at;
               float idv[8];
-              join16x8(*reinterpret_cast<const uint4*>(xp), *reinterpret_cast<const uint4*>(xp + 64), idv);
+              join16x8(idp[i][ps][0], idp[i][ps][1], idv);
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] = __builtin_elementwise_maximum(v[q] + idv[q], 0.f);
               uint4 o0, o1;

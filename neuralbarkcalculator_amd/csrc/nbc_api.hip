@@ -97,7 +97,7 @@ struct nbc_ctx {
 namespace {
 
 constexpr size_t kPlanCacheEntries = 64;
-constexpr int kDefaultFuseMask = 0x1f;      // all five (layer1.1, layer1.2, layer2.1, layer2.2, layer2.3)
+constexpr int kDefaultFuseMask = 0;         // off: measured within +-1.5 % of the three convolutions (profiles/r03_fused_bottleneck_f16x2.log)
 
 bool same_shape(const Plan& p, int N, int H, int W, int precision, bool keep) {
   return p.N == N && p.H == H && p.W == W && p.precision == precision && p.keep == keep;
