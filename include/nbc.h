@@ -200,11 +200,11 @@ int nbc_resize_cubic_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, floa
 int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_u8_dev, int32_t* row_lit_dev,
                       int out_h, int out_w, void* hip_stream);
 
-/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..14 = 128x64, 128x128,
+/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..15 = 128x64, 128x128,
  * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave
  * 128x128 and 128x64, the 16-wave 256x128 and (bf16) the 16-wave 256x256, the 8-wave 128x128 of 64x32 wave tiles and
- * (f16x2) the same with four loader waves (pixels x channels), forced wherever the layer's Cout and the precision
- * allow it. */
+ * (f16x2) the same and the 8-wave 128x64 with four loader waves each (pixels x channels), forced wherever the layer's
+ * Cout and the precision allow it. */
 int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
 
 /* Sub-batched tail.  With N images per call the 2048-channel residual stream of layer4 is 67 MB per image in bf16

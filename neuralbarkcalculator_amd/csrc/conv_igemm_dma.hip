@@ -915,6 +915,8 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //                                                               accumulator sets allow wave tiles of 64x32 at most)
 //   14  128x128   2x4 + 4        64x32      3       96 KiB   1   (f16x2 only: tile 13 with four loader waves, VAR 8; 8-11 %
 //                                                               faster on the 3x3 and long-K 1x1 layers)
+//   15  128x64    4x2 + 4        32x32      3       72 KiB   1   (f16x2 only: tile 10 with four loader waves; layer2's 3x3 at
+//                                                               batch 1, one block per CU anyway: 27 -> 24 us)
 //   12  256x256   4x4            64x64      2       128 KiB  1   (bf16: short-K layers at batch >= 2; the matrix pipe is
 //                                                               busier than with 8 waves, the clock lower: same TFLOP/s on
 //                                                               long-K layers, 2-5 % faster epilogue-heavy 1x1 layers)
@@ -930,6 +932,7 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
       case 10: return launch_cfg<PREC, 4, 2, 1, 1, 3, STEM, VAR>(a, s);
       case 13: return launch_cfg<PREC, 2, 4, 2, 1, 3, STEM, VAR>(a, s);
       case 14: return launch_cfg<PREC, 2, 4, 2, 1, 3, STEM, STEM ? VAR : 8>(a, s);     // 13 with four loader waves
+      case 15: return launch_cfg<PREC, 4, 2, 1, 1, 3, STEM, STEM ? VAR : 8>(a, s);     // 10 with four loader waves
       default: return hipErrorInvalidValue;
     }
   } else
@@ -956,8 +959,8 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64};
 
 }  // namespace
 
@@ -968,8 +971,8 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 bool conv_tile_ok(int precision, int tile, int Co) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
   if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
-  if (precision == 2 && !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || tile == 10 || tile == 13 || tile == 14)) return false;
-  if (precision != 2 && tile == 14) return false;                  // the loader-wave tile is f16x2's (in bf16 a 256x128 tile
+  if (precision == 2 && !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || tile == 10 || tile >= 13)) return false;
+  if (precision != 2 && tile >= 14) return false;                  // the loader-wave tile is f16x2's (in bf16 a 256x128 tile
                                                                    // with loader waves ties the one without: section 6.4)
   return Co % kTileCols[tile] == 0;
 }
@@ -992,21 +995,21 @@ struct TileModel {
 constexpr TileModel kTileModel[3] = {
     // f32: 157.3 TF / 256 CUs
     {157.3e6 / 256.0,
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80},
-     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80},
+     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
     // bf16: against the 1 400 TF/s the chip sustains on this kernel (power-limited), / 256 CUs
     {1400.0e6 / 256.0,
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80},
-     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0},
-     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0}},
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80},
+     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0},
+     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0}},
     // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs; fitted to
-    // eight (batch, height) cases (profiles/r03_tile_model_data_f16x2_*.json, r03_tile_model_fit_f16x2.log): 1.2-2.9 % from
+    // eight (batch, height) cases (profiles/r03_tile_model_data_f16x2_*.json, r03_tile_model_fit_f16x2.log): 1.2-2.5 % from
     // the per-layer best
     {839.0e6 / 256.0,
-     {0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.54},
-     {3, 3, 3, 3, 3, 3, 3.403, 1.77, 1.494, 2.995, 1.691, 3, 3, 3, 3.673},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+     {0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.516, 0.5, 0.529, 0.5, 0.5, 0.5, 0.532, 0.5},
+     {3, 3, 3, 3, 3, 3, 3.422, 1.875, 1.495, 3, 1.746, 3, 3, 3, 3.293, 3},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
 }  // namespace
 
 int choose_conv_tile(int M, int Co, int K, int precision) {

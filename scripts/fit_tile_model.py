@@ -13,28 +13,28 @@ import math
 import random
 import sys
 
-ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128]
-COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128]
+ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128]
+COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64]
 NT = len(ROWS)
 # FLOPs per ms per CU the efficiencies refer to (f16x2: algorithmic FLOPs, three f16 MFMA FLOPs each: 2 517 / 3)
 PEAK = {"fp32": 157.3e12 / 256 * 1e-3, "bf16": 1400e12 / 256 * 1e-3, "f16x2": 839e12 / 256 * 1e-3}
 BYTE_MS = 1.0 / (50e9 * 1e-3)                                                # ms per byte at 50 GB/s
 MODEL = {
-    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80],
-                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * NT),
-    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80],
-                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0],
-                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0]),
-    "f16x2": dict(eff=[0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.54],
-                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.403, 1.77, 1.494, 2.995, 1.691, 3.0, 3.0, 3.0, 3.673], cb=[0.0] * NT),
+    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80],
+                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * NT),
+    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80],
+                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0],
+                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
+    "f16x2": dict(eff=[0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.516, 0.5, 0.529, 0.5, 0.5, 0.5, 0.532, 0.5],
+                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.422, 1.875, 1.495, 3.0, 1.746, 3.0, 3.0, 3.0, 3.293, 3.0], cb=[0.0] * NT),
 }
-F16X2_TILES = (0, 6, 7, 8, 9, 10, 13, 14)
+F16X2_TILES = (0, 6, 7, 8, 9, 10, 13, 14, 15)
 
 
 def tile_ok(prec, t, co):
     if prec == "f16x2" and t not in F16X2_TILES:
         return False
-    if prec != "f16x2" and t == 14:
+    if prec != "f16x2" and t >= 14:
         return False
     return not (prec == "fp32" and t in (3, 12)) and co % COLS[t] == 0
 
@@ -96,10 +96,12 @@ def regret(data, prec, p, verbose=False):
     return s / max(n, 1)
 
 
-def fit(data, prec, iters=8000, seed=1, lam=0.002):
+def fit(data, prec, iters=8000, seed=1, lam=0.002, start=None):
     random.seed(seed)
     p = dict(eff=[0.5 if prec == "f16x2" else 0.85] * NT, ovh=[3.0 if prec == "f16x2" else 4.0] * NT, cb=[1.0 if prec == "bf16" else 0.0] * NT)
     prior = {k: list(v) for k, v in p.items()}
+    if start is not None:                 # --from-model: refine the compiled constants (e.g. after a tile joined the menu)
+        p = {k: list(v) for k, v in start.items()}
 
     def score(q):
         pen = sum((a - b) ** 2 for a, b in zip(q["eff"], prior["eff"])) + 0.01 * sum((a - b) ** 2 for a, b in zip(q["ovh"], prior["ovh"])) \
@@ -136,7 +138,7 @@ def main():
                     p = fit(a, prec, iters=4000)
                     print("%s cross-validation %s: mean regret %.2f %% on the fitted file, %.2f %% on the other"
                           % (prec, tag, regret(a, prec, p) * 100, regret(b, prec, p) * 100))
-            p = fit(everything, prec)
+            p = fit(everything, prec, iters=20000, start=MODEL[prec] if "--from-model" in sys.argv else None)
             print(prec, "fitted on all cases:", json.dumps({k: [round(v, 3) for v in vs] for k, vs in p.items()}))
         else:
             p = MODEL[prec]

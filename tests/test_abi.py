@@ -212,18 +212,18 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
 def test_default_conv_tile_cost_model(built_lib):
     """Host logic of the per-layer default tile (csrc/conv_igemm_dma.hip, choose_conv_tile): a valid tile for the
     precision and channel count, and the choices that matter most, where whole rounds of blocks on 256 CUs decide."""
-    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128]
-    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128]
+    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128]
+    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64]
     f = built_lib.nbc_default_conv_tile
     for prec in (0, 1, 2):
         for co in (64, 128, 256, 512, 1024, 2048):
             for m in (64, 1000, 8448, 9984, 16384, 65536, 131072, 524288):
                 for k in (64, 576, 2048, 18432):
                     t = f(m, co, k, prec)
-                    assert 0 <= t < 15 and co % cols[t] == 0
+                    assert 0 <= t < 16 and co % cols[t] == 0
                     assert not (prec == 0 and t in (3, 12))            # f32 has no 256x256 tile
-                    assert prec != 2 or t in (0, 6, 7, 8, 9, 10, 13, 14)   # f16x2: wave tiles of 64x32 at most
-                    assert prec == 2 or t != 14                            # the loader-wave tile is f16x2's
+                    assert prec != 2 or t in (0, 6, 7, 8, 9, 10, 13, 14, 15)   # f16x2: wave tiles of 64x32 at most
+                    assert prec == 2 or t < 14                             # the loader-wave tiles are f16x2's
     assert f(16384, 96, 64, 0) == -1 and f(16384, 512, 64, 7) == -1 and f(0, 512, 64, 0) == -1
     blocks = lambda t, m, co: -(-m // rows[t]) * (co // cols[t])
     # the head conv (3x3, 2048 -> 512) in f32 at 1024x1024: 16 384 pixels, one 256x128 / 128x256 tile per CU
