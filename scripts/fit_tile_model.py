@@ -25,7 +25,7 @@ MODEL = {
     "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80],
                  ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0],
                  cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
-    "f16x2": dict(eff=[0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.516, 0.5, 0.529, 0.5, 0.5, 0.5, 0.532, 0.5],
+    "f16x2": dict(eff=[0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.516, 0.5, 0.529, 0.5, 0.5, 0.5, 0.54, 0.5],
                   ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.422, 1.875, 1.495, 3.0, 1.746, 3.0, 3.0, 3.0, 3.293, 3.0], cb=[0.0] * NT),
 }
 F16X2_TILES = (0, 6, 7, 8, 9, 10, 13, 14, 15)
