@@ -133,7 +133,8 @@ def test_two_rank_folder_over_rccl(tmp_path, sd_np, built_lib):
 def test_two_rank_folder_rehearsal_on_one_gpu(tmp_path, sd_np, built_lib, n_images):
     """The multi-rank folder path on a one-GPU box: two ranks (torch.distributed.run, gloo) that both use cuda:0.
     Rank 0 alone reads the checkpoint, the packed weights travel by broadcast, each rank predicts its contiguous
-    pixel-balanced shard, the rows are gathered and rank 0 writes the CSV: same files as one rank."""
+    pixel-balanced shard, the rows are gathered and rank 0 writes the CSV: same files as one rank.  In the f16x2 mode (the
+    CLI's default), whose non-finite flag travels through one more scalar all-reduce before the gather."""
     import subprocess
     import sys
     layout = [("epinette_gelee" if i < 4 else "sapin", "s%02d.bmp" % i, 60 + i, 96 + 8 * (i % 4), 160) for i in range(n_images)]
@@ -146,7 +147,7 @@ def test_two_rank_folder_rehearsal_on_one_gpu(tmp_path, sd_np, built_lib, n_imag
                 "sys.path.insert(0, %r)\n"
                 "from neuralbarkcalculator_amd import predict\n"
                 "dist.init_process_group('gloo')\n"
-                "st = predict.predict_folder(%r, %r, device_index=0)\n"
+                "st = predict.predict_folder(%r, %r, precision='f16x2', device_index=0)\n"
                 "assert st['world'] == %d and st['images_total'] == %d\n"
                 "dist.destroy_process_group()\n" % (repo, root, ckpt, world, n_images))
         script = tmp_path / ("run%d.py" % world)
