@@ -552,7 +552,8 @@ int nbc_nonfinite_seen(nbc_ctx* c, int reset) {
   if (!c->nonfinite) return 0;                       // no forward yet
   NBC_HIP(hipSetDevice(c->device));
   unsigned v = 0;
-  NBC_HIP(hipMemcpy(&v, c->nonfinite, sizeof(v), hipMemcpyDeviceToHost));      // waits for the device: every forward has finished
+  NBC_HIP(hipDeviceSynchronize());                   // every forward on every stream (non-blocking ones too) has finished
+  NBC_HIP(hipMemcpy(&v, c->nonfinite, sizeof(v), hipMemcpyDeviceToHost));
   if (reset && v) NBC_HIP(hipMemset(c->nonfinite, 0, sizeof(v)));
   return v ? 1 : 0;
 }
