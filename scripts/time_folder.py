@@ -6,7 +6,8 @@ PNG, CSV.  usage: python scripts/time_folder.py [n_images=1000] [precisions=bf16
 the reference's real folders look like: res/*.png): hundreds of distinct image shapes in one folder.
 "raw": raw scans of 4096x4096 pixels with the same black bands (48 MB per .bmp): the whole preprocessor runs (cubic
 resize to 1024x1024 on the GPU, trim_black, processed/ PNG) before the forward.
-NBC_HOST_WORKERS sets the host thread pool (default 16, the GPU box's CPU share per GPU)."""
+NBC_HOST_WORKERS sets the host thread pool (default 16, the GPU box's CPU share per GPU); NBC_STREAMS / NBC_BATCH override
+the driver's batches in flight and frames per batch."""
 import json
 import os
 import shutil
@@ -58,7 +59,9 @@ try:
             shutil.rmtree(os.path.join(root, "results"), ignore_errors=True)
             shutil.rmtree(os.path.join(root, "processed"), ignore_errors=True)
             t0 = time.perf_counter()
-            st = drv.predict_folder(root, ckpt, precision=prec, device_index=0, window=int(os.environ.get("NBC_WINDOW", "64")))
+            st = drv.predict_folder(root, ckpt, precision=prec, device_index=0, window=int(os.environ.get("NBC_WINDOW", "64")),
+                                    streams=int(os.environ["NBC_STREAMS"]) if "NBC_STREAMS" in os.environ else None,
+                                    batch=int(os.environ["NBC_BATCH"]) if "NBC_BATCH" in os.environ else None)
             dt = time.perf_counter() - t0
             rows = open(os.path.join(root, "results", "final_stats.csv")).read().count("\n") - 1
             print(f"{prec} run {rep}: {n} images end to end in {dt:.2f} s = {n / dt:.1f} images/s "
