@@ -73,7 +73,11 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=2,
                     help="independent forwards kept in flight on separate HIP streams (each its own workspace)")
     ap.add_argument("--weights", choices=["random_init", "trained_like"], default="trained_like")
-    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames cycled through")
+    ap.add_argument("--frames", type=int, default=100,
+                    help="distinct synthetic frames resident in HBM and cycled through by the steps (configs[1] names 100: "
+                         "1.26 GB as f32 NCHW)")
+    ap.add_argument("--parity-frames", type=int, default=4,
+                    help="distinct frames the parity objects compare with the CPU oracle (the bf16 batch-8 leg uses 8)")
     ap.add_argument("--conv-tile", type=int, default=-1, help="-1 = per-layer choice, 0.. force a tile shape (A/B runs)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -92,12 +96,6 @@ def parse(argv=None):
     ap.add_argument("--f32-streams", type=int, default=4)
     ap.add_argument("--bf16-steps", type=int, default=0, help="steps of the configs[2] leg (default: max(10, K/5))")
     ap.add_argument("--bf16-streams", type=int, default=2)
-    ap.add_argument("--sub-batch", default="auto",
-                    help="sub-batched tail of a leg with batch > 1: 'auto' (the library's default), 'off', or "
-                         "'<first op>:<images>', e.g. backbone.layer4.0.conv1:2")
-    ap.add_argument("--fusion", type=int, default=-1,
-                    help="f16x2: bottlenecks run as one fused launch, bits 0..4 = layer1.1, layer1.2, layer2.1, layer2.2, layer2.3 "
-                         "(-1 = the library's default, 0 = none)")
     ap.add_argument("--no-op-events", action="store_true", help="no instrumented region (no roofline object)")
     ap.add_argument("--save-tiles", default=None, help="write the measured per-layer tile choices (JSON) to this file")
     ap.add_argument("--tiles-file", default=None,
@@ -213,7 +211,11 @@ def main():
     sd = synth.make_state_dict(args.weights, seed=7) if rank == 0 else None
     nf = max(1, args.frames)
     # frames: each rank owns its shard of the folder (rank r takes global images r, r+world, ...)
-    frames = [synth.make_input(rank + world * i, H, W) for i in range(nf)]
+    # (generated on a few host threads: 0.3-0.5 s per frame on one)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, host_cores())) as pool:
+        frames = list(pool.map(lambda i: synth.make_input(rank + world * i, H, W), range(nf)))
+    frames_dev = None                                # the same frames in HBM, shared by the legs
 
     def run_leg(precision, batch, nstreams, steps, warmup, instrument):
         """One configuration: weights to every rank, workspace, per-layer tiles, W warm-up steps, the
@@ -234,18 +236,13 @@ def main():
             leg["setup"]["weight_broadcast_s"] = max_over_ranks(time.perf_counter() - t0)
             leg["setup"]["weight_blob_bytes"] = int(model._blob_dev.numel())
         t0 = time.perf_counter()
-        batches = []
-        for i in range(nf):
-            b = np.stack([frames[(i + j) % nf] for j in range(batch)])
-            batches.append(torch.from_numpy(b).to(dev))
-        def apply_sub_batch(m):
-            if args.sub_batch == "off":
-                m.set_sub_batch(None, 0)
-            elif args.sub_batch != "auto":
-                name, n = args.sub_batch.rsplit(":", 1)
-                m.set_sub_batch(name, int(n))
-        apply_sub_batch(model)
-        model.set_fusion(args.fusion)
+        nonlocal frames_dev
+        if frames_dev is None:
+            frames_dev = [torch.from_numpy(f).to(dev) for f in frames]
+        if batch == 1:
+            batches = [f[None] for f in frames_dev]                  # views: nothing is copied
+        else:                                        # batch i = frames i, i+1, ... (cyclically), stacked on the device
+            batches = [torch.stack([frames_dev[(i + j) % nf] for j in range(batch)]) for i in range(min(nf, steps + warmup))]
         model.reserve(batch, H, W)
         model.set_conv_tile(args.conv_tile)
         tiles = None
@@ -263,8 +260,6 @@ def main():
         models = [model]
         for _ in range(nstreams - 1):
             m2 = model.clone_shared()
-            apply_sub_batch(m2)
-            m2.set_fusion(args.fusion)
             m2.reserve(batch, H, W)
             m2.set_conv_tile(args.conv_tile)
             if tune:
@@ -280,7 +275,7 @@ def main():
         def step(i, k=None):
             k = i % nstreams if k is None else k
             with torch.cuda.stream(streams[k]):
-                return models[k].predict_labels(batches[i % nf], labels_dtype=torch.uint8)
+                return models[k].predict_labels(batches[i % len(batches)], labels_dtype=torch.uint8)
 
         def timed_region(n_steps, k=None):
             barrier()
@@ -366,6 +361,11 @@ def main():
             t = json.load(open(path))
             if t.get("batch") == leg["batch"] and t.get("precision") == prec and t.get("kernel_source_id") == kernel_source_id():
                 out["traffic"] = t["dominant_kernel"]["traffic_bytes_per_launch"]
+                # the same kernel's figure by rocprofv3 --kernel-trace (medians over the forwards of the same command): the
+                # raw HIP events of `frac` include an event packet per launch (about 3 us on launches of 70-170 us)
+                if "frac_of_peak" in t["dominant_kernel"]:
+                    out["frac_rocprof_table"] = t["dominant_kernel"]["frac_of_peak"]
+                    out["table"] = "profiles/%s" % os.path.basename(path)
                 out["traffic_note"] = ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch of the dominant kernel (separate PMC passes, "
                                        "L2-miss traffic incl. Infinity-Cache hits), from profiles/%s" % os.path.basename(path))
                 if "mfma_util" in t["dominant_kernel"]:     # matrix-pipe utilisation by hardware counters, same table
@@ -473,32 +473,38 @@ def main():
         return ref_cache[frame_idx]
 
     def parity_of(model, frame_ids, batch):
-        """Labels of `model` on the given frames (run as ONE batch of that size, padded by cycling) vs the oracle."""
-        ids = [frame_ids[j % len(frame_ids)] for j in range(batch)]
-        x = torch.from_numpy(np.stack([frames[i] for i in ids])).to(dev)
-        labels, counts, lowres = model.predict_labels(x, return_lowres=True)
-        torch.cuda.synchronize()
-        res = {"frames": "synthetic frames %s of rank 0, run as one batch of %d" % (sorted(set(ids)), batch),
+        """Labels and low-res logits of `model` on the given distinct frames, run in batches of `batch` (the last one
+        padded by cycling), against the CPU oracle frame by frame."""
+        res = {"frames": "synthetic frames %s of rank 0, run in batches of %d" % (list(frame_ids), batch),
                "precision": model.precision, "pixels": 0, "label_mismatches": 0, "max_oracle_margin_at_mismatch": 0.0,
-               "max_lowres_logit_err_over_oracle_range": 0.0}
-        for j, i in enumerate(ids[:len(set(ids))]):
-            labels_ref, counts_ref, logits_ref, lowres_ref = oracle_on(i)
-            res["max_lowres_logit_err_over_oracle_range"] = max(
-                res["max_lowres_logit_err_over_oracle_range"],
-                float((lowres[j].cpu() - lowres_ref[0]).abs().max()) / float(logits_ref.abs().max()))
-            bad = labels[j].cpu() != labels_ref[0]
-            top2 = torch.topk(logits_ref, 2, dim=1).values
-            margin = (top2[:, 0] - top2[:, 1])[0]
-            res["pixels"] += int(bad.numel())
-            res["label_mismatches"] += int(bad.sum())
-            if bool(bad.any()):
-                res["max_oracle_margin_at_mismatch"] = max(res["max_oracle_margin_at_mismatch"], float(margin[bad].max()))
-            res["oracle_logit_range"] = float(logits_ref.abs().max())
-            res.setdefault("oracle_class_counts", counts_ref[0].tolist())
-            res.setdefault("gpu_class_counts", counts[j].cpu().tolist())
+               "max_lowres_logit_err_over_oracle_range": 0.0, "frames_compared": 0, "per_frame_label_mismatches": []}
+        for a in range(0, len(frame_ids), batch):
+            chunk = list(frame_ids[a:a + batch])
+            ids = [chunk[j % len(chunk)] for j in range(batch)]
+            x = torch.stack([frames_dev[i] for i in ids])
+            labels, counts, lowres = model.predict_labels(x, return_lowres=True)
+            torch.cuda.synchronize()
+            for j, i in enumerate(chunk):
+                labels_ref, counts_ref, logits_ref, lowres_ref = oracle_on(i)
+                res["max_lowres_logit_err_over_oracle_range"] = max(
+                    res["max_lowres_logit_err_over_oracle_range"],
+                    float((lowres[j].cpu() - lowres_ref[0]).abs().max()) / float(logits_ref.abs().max()))
+                bad = labels[j].cpu() != labels_ref[0]
+                top2 = torch.topk(logits_ref, 2, dim=1).values
+                margin = (top2[:, 0] - top2[:, 1])[0]
+                res["pixels"] += int(bad.numel())
+                res["label_mismatches"] += int(bad.sum())
+                res["per_frame_label_mismatches"].append(int(bad.sum()))
+                res["frames_compared"] += 1
+                if bool(bad.any()):
+                    res["max_oracle_margin_at_mismatch"] = max(res["max_oracle_margin_at_mismatch"], float(margin[bad].max()))
+                res["oracle_logit_range"] = float(logits_ref.abs().max())
+                res.setdefault("oracle_class_counts", counts_ref[0].tolist())
+                res.setdefault("gpu_class_counts", counts[j].cpu().tolist())
         res["label_match"] = 1.0 - res["label_mismatches"] / max(1, res["pixels"])
         return res
 
+    n_par = max(1, min(args.parity_frames, nf))
     if world == 1 and not args.no_cpu_baseline:
         # the oracle (a port of the reference's torch-CPU forward, eval mode) + argmax on this box's host
         # cores: 1 warm-up + 3 timed calls on ONE 1024x1024 frame (about 10-30 s of CPU work)
@@ -516,7 +522,7 @@ def main():
                                          "median of 3" % torch.__version__,
                                "s_per_image": med}
     if world == 1 and not args.no_parity:
-        out["parity"] = parity_of(head["model"], [0], args.batch)
+        out["parity"] = parity_of(head["model"], list(range(n_par)), args.batch)
     if legf is not None:
         of = {
             "config": {"workload": "configs[1]: 1xMI355X per rank, batch=1, f32 activations/weights on v_mfma_f32_32x32x2_f32 (round 2's "
@@ -530,7 +536,7 @@ def main():
             of["roofline"] = roofline_of(legf)
             of["top_ops"] = of["roofline"].pop("top_ops")
         if world == 1 and not args.no_parity:
-            of["parity"] = parity_of(legf["model"], [0], 1)
+            of["parity"] = parity_of(legf["model"], list(range(n_par)), 1)
         out["f32_mfma_batch1"] = of
     if leg8 is not None:
         o8 = {
@@ -545,7 +551,7 @@ def main():
             o8["roofline"] = roofline_of(leg8)
             o8["top_ops"] = o8["roofline"].pop("top_ops")
         if world == 1 and not args.no_parity:
-            o8["parity"] = parity_of(leg8["model"], [0, 1], 8)
+            o8["parity"] = parity_of(leg8["model"], list(range(min(nf, max(8, n_par)))), 8)
         out["bf16_batch8"] = o8
     sys.stdout.flush()
     os.write(line_fd, (json.dumps(out) + "\n").encode())

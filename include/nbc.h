@@ -97,7 +97,7 @@ typedef struct {
   double bytes;       /* algorithmic: input read once + weights once + output once (+ identity) */
   int32_t kh, kw;     /* kernel extent (0 for non-conv) */
   int32_t cout;       /* output channels (conv ops): Co % 128 == 0 selects the wide-tile kernel */
-  int32_t launches;   /* launches of the op per forward: 1, or the number of sub-batches (nbc_set_sub_batch) */
+  int32_t launches;   /* launches of the op per forward (1) */
 } nbc_op_record;
 
 const char* nbc_last_error(void);
@@ -207,22 +207,6 @@ int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_
  * Cout and the precision allow it. */
 int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
 
-/* Sub-batched tail.  With N images per call the 2048-channel residual stream of layer4 is 67 MB per image in bf16
- * (134 MB in f32): at N = 8 every 1x1 + identity launch streams 1.2 GB through HBM.  After this call the plan runs
- * the ops in front of `first_op` once on the whole batch and everything from `first_op` to classifier.4 depth-first on
- * `images` images at a time, in buffers sized for (and re-used by) one sub-batch, so that those tensors stay in the
- * 256-MB Infinity Cache.  Same kernels, same K order: results are bit-identical to the whole-batch plan.
- * `first_op` is the first convolution of a bottleneck ("backbone.layer3.0.conv1", ...) or "classifier.0";
- * NULL or images < 1 turns it off (the default).  Calls with N <= images, and keep-activations mode, run whole-batch. */
-int nbc_set_sub_batch(nbc_ctx* ctx, const char* first_op, int images);
-
-/* Whole-bottleneck fusion (NBC_PREC_F16X2): the five bottlenecks without downsample of layer1 and layer2 (layer1.1,
- * layer1.2, layer2.1, layer2.2, layer2.3 = bits 0..4 of `mask`) run as ONE launch each instead of three convolutions
- * (x read once, t1 and t2 never leave LDS), bit-identical to them.  mask -1 = the library's default, 0 = off.
- * stop_after 1 / 2 is for tests: the fused launch ends behind conv1 / conv2 and the unfused convolutions finish the block.
- * Other precisions and keep-activations plans always run the three convolutions. */
-int nbc_set_fusion(nbc_ctx* ctx, int mask, int stop_after);
-
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real
  * activations), then times every tile shape of the LDS-DMA kernel on every convolution of the
  * current (N,H,W) plan (`reps` launches each, HIP events) and keeps the fastest.  Results do not
@@ -251,6 +235,11 @@ int nbc_set_plan_tiles(nbc_ctx* ctx, const int32_t* tiles, int n);
  * that mode cannot represent: a caller that runs unknown weights in f16x2 checks this after its last forward and falls
  * back to NBC_PREC_FP32 when it is raised (the folder driver does).  Synchronises the device. */
 int nbc_nonfinite_seen(nbc_ctx* ctx, int reset);
+/* The same word without a synchronisation: enqueues on hip_stream a copy of it to *host_dst (pinned host memory), valid
+ * once work enqueued behind it on that stream has been waited for; non-zero = raised by a forward that ran on this
+ * context ahead of the copy.  The folder driver sends it along with every batch's labels, so that an f16x2 run of
+ * weights that mode cannot carry is abandoned at the first batch that shows it, not after the last. */
+int nbc_nonfinite_peek_async(nbc_ctx* ctx, uint32_t* host_dst, void* hip_stream);
 
 /* ---- debugging / measurement ----------------------------------------------------------- */
 /* Copy the activation written by conv unit `name` during the last forward to `dst_host` as

@@ -56,9 +56,8 @@ SIGNATURES = {
     "nbc_load_weights": (C.c_int, [C.c_void_p, C.POINTER(NbcTensor), C.c_int, C.c_int]),
     "nbc_set_normalization": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "nbc_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
-    "nbc_set_sub_batch": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "nbc_nonfinite_seen": (C.c_int, [C.c_void_p, C.c_int]),
-    "nbc_set_fusion": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nbc_nonfinite_peek_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "nbc_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                               C.c_void_p]),

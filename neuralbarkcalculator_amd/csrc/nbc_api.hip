@@ -28,7 +28,7 @@ namespace {
       return set_error(NBC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
   } while (0)
 
-enum OpKind { OP_INGEST, OP_CONV, OP_MAXPOOL, OP_HEAD1X1, OP_UPSAMPLE, OP_BOTTLENECK };
+enum OpKind { OP_INGEST, OP_CONV, OP_MAXPOOL, OP_HEAD1X1, OP_UPSAMPLE };
 
 struct Op {
   OpKind kind;
@@ -38,8 +38,6 @@ struct Op {
   std::string name;
   double flops, bytes;
   int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
-  bool in_full, res_full;   // sub-batched tail: the input / identity buffer holds the whole batch (the image offset applies)
-  int stop_after;           // OP_BOTTLENECK: 0 = the whole bottleneck (unit = its conv1); 1 / 2 (tests): t1 / t2 into out_buf
 };
 
 struct Plan {
@@ -48,13 +46,6 @@ struct Plan {
   int h = 0, w = 0;                    // low-res logits size
   std::vector<Op> ops;
   std::vector<size_t> buf_bytes;       // per activation buffer
-  // Sub-batched tail (nbc_set_sub_batch): ops [0, sub_from) run once on all N images, ops [sub_from, upsample)
-  // run depth-first on sub_n images at a time in buffers sized (and re-used) for sub_n images, so that the
-  // wide residual stream of layer3 / layer4 stays in the 256-MB Infinity Cache; -1 = the whole plan on N images.
-  int sub_from = -1, sub_n = 0;
-  std::string sub_first;               // the request the plan was built for (part of its identity)
-  int sub_req = 0;
-  int fuse_mask = 0, fuse_stop = 0;    // likewise: nbc_set_fusion
 };
 
 }  // namespace
@@ -74,10 +65,6 @@ struct nbc_ctx {
   float* lowres = nullptr;
   size_t lowres_cap = 0;
   int conv_tile = -1;                       // tile override, -1 = per-layer choice
-  std::string sub_first;                    // sub-batched tail: its first op ("" = none) ...
-  int sub_n = 0;                            // ... and images per sub-batch (nbc_set_sub_batch)
-  int fuse_mask = -1;                       // f16x2: which of the five fusable bottlenecks run as one launch (nbc_set_fusion); -1 = default
-  int fuse_stop = 0;                        // tests: the fused launch stops behind conv1 / conv2, the unfused rest follows
   bool keep = false;
   bool profiling = false;
   // profiling: one event set (nops+1 events) per profiled forward, read back lazily so that the
@@ -85,7 +72,6 @@ struct nbc_ctx {
   std::vector<std::vector<hipEvent_t>> prof_sets;
   size_t prof_used = 0;
   std::vector<Op> prof_ops;
-  std::vector<int> prof_launch_op;          // op index of each launch of a profiled forward (sub-batches repeat ops)
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
   void* scratch256 = nullptr;               // 256 bytes of device scratch (min/max of the preprocessor resize)
@@ -97,14 +83,12 @@ struct nbc_ctx {
 namespace {
 
 constexpr size_t kPlanCacheEntries = 64;
-constexpr int kDefaultFuseMask = 0;         // off: measured within +-1.5 % of the three convolutions (profiles/r03_fused_bottleneck_f16x2.log)
 
 bool same_shape(const Plan& p, int N, int H, int W, int precision, bool keep) {
   return p.N == N && p.H == H && p.W == W && p.precision == precision && p.keep == keep;
 }
 bool same_plan(const Plan& p, const nbc_ctx* c, int N, int H, int W) {
-  return same_shape(p, N, H, W, c->precision, c->keep) && p.sub_first == c->sub_first && p.sub_req == c->sub_n &&
-         p.fuse_mask == c->fuse_mask && p.fuse_stop == c->fuse_stop;
+  return same_shape(p, N, H, W, c->precision, c->keep);
 }
 
 // Park the current plan (folders of height-trimmed images alternate between a few shapes: each keeps
@@ -113,8 +97,7 @@ void stash_plan(nbc_ctx* c) {
   Plan& cur = c->plan;
   if (cur.N == 0) return;
   for (Plan& p : c->plan_cache)
-    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep) && p.sub_first == cur.sub_first && p.sub_req == cur.sub_req &&
-        p.fuse_mask == cur.fuse_mask && p.fuse_stop == cur.fuse_stop) {
+    if (same_shape(p, cur.N, cur.H, cur.W, cur.precision, cur.keep)) {
       p = cur; cur = Plan(); return;
     }
   if (c->plan_cache.size() >= kPlanCacheEntries) c->plan_cache.erase(c->plan_cache.begin());
@@ -127,14 +110,6 @@ void stash_plan(nbc_ctx* c) {
 int build_plan(nbc_ctx* c, int N, int H, int W) {
   Plan P;
   P.N = N; P.H = H; P.W = W; P.precision = c->precision; P.keep = c->keep;
-  P.sub_first = c->sub_first; P.sub_req = c->sub_n;
-  P.fuse_mask = c->fuse_mask; P.fuse_stop = c->fuse_stop;
-  // the tail runs in sub-batches when one is asked for, it is smaller than the batch, and every op keeps its own
-  // buffer for the whole batch is not asked for (layer-by-layer tests read whole-batch activations)
-  const bool want_sub = !c->sub_first.empty() && c->sub_n >= 1 && c->sub_n < N && !c->keep;
-  bool in_tail = false;                // set when the op named sub_first is reached
-  int boundary = -1;                   // the whole-batch buffer the tail starts from: never recycled inside the tail
-  int NB = N;                          // images per launch of the ops being added
   const int eb = elem_bytes(c->precision);
   const auto& units = conv_units();
   const auto& L = c->layout;
@@ -148,7 +123,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     P.buf_bytes.push_back(bytes);
     return (int)in_use.size() - 1;
   };
-  auto release = [&](int b) { if (b >= 0 && !P.keep && b != boundary) in_use[b] = false; };
+  auto release = [&](int b) { if (b >= 0 && !P.keep) in_use[b] = false; };
 
   auto conv_out = [](int x, int k, int s, int p, int d) { return (x + 2 * p - d * (k - 1) - 1) / s + 1; };
 
@@ -167,16 +142,11 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     const ConvUnit& u = units[ui];
     const int Ho = conv_out(inH, u.k, u.stride, u.pad, u.dil);
     const int Wo = conv_out(inW, u.k, u.stride, u.pad, u.dil);
-    if (want_sub && !in_tail && c->sub_first == u.name) {   // the tail starts here, from the buffer this op reads
-      in_tail = true; boundary = in_buf; NB = c->sub_n;
-      P.sub_from = (int)P.ops.size(); P.sub_n = NB;
-    }
     Op o{};
     o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
-    o.in_full = in_tail && in_buf == boundary; o.res_full = in_tail && res_buf >= 0 && res_buf == boundary;
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
-    o.out_buf = acquire((size_t)NB * Ho * Wo * u.cout * eb);
-    o.tile = choose_conv_tile(NB * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision);
+    o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
+    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
     o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +
@@ -205,52 +175,8 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     ui = 1;
   }
   // bottlenecks
-  int fusable = 0;                     // running index of the bottlenecks the fused kernel covers (bits of fuse_mask)
   while (ui < units.size() && units[ui].block_first) {
     int h1, w1, h2, w2, h3, w3;
-    // f16x2: a bottleneck without downsample, stride and dilation 1, 64 or 128 mid channels (layer1.1-2, layer2.1-3)
-    // runs as ONE launch (bottleneck_fused.hip), bit-identical to its three convolutions; keep-activations plans keep
-    // the three (the layer-by-layer tests read conv1 / conv2)
-    const bool shape_ok = units[ui + 2].residual && units[ui + 1].stride == 1 && units[ui + 1].dil == 1 &&
-                          (units[ui].cout == 64 || units[ui].cout == 128) && units[ui].cin == 4 * units[ui].cout;
-    if (shape_ok) {
-      const int bit = fusable++;
-      const int mask = c->fuse_mask < 0 ? kDefaultFuseMask : c->fuse_mask;
-      if (c->precision == NBC_PREC_F16X2 && !P.keep && ((mask >> bit) & 1)) {
-        const int cm = units[ui].cout, c4 = 4 * cm;
-        if (want_sub && !in_tail && c->sub_first == units[ui].name) {
-          in_tail = true; boundary = cur; NB = c->sub_n;
-          P.sub_from = (int)P.ops.size(); P.sub_n = NB;
-        }
-        const int stop = c->fuse_stop;
-        Op o{};
-        o.kind = OP_BOTTLENECK; o.unit = (int)ui; o.in_buf = cur; o.res_buf = -1; o.stop_after = stop;
-        o.in_full = in_tail && cur == boundary;
-        o.Hi = curH; o.Wi = curW; o.Ci = c4; o.Ho = curH; o.Wo = curW; o.Co = stop ? cm : c4;
-        const std::string block = units[ui].name.substr(0, units[ui].name.rfind('.'));
-        o.name = block + (stop == 1 ? ".fused_conv1" : stop == 2 ? ".fused_conv1_conv2" : ".fused");
-        o.out_buf = acquire((size_t)NB * curH * curW * o.Co * eb);
-        const double M = (double)N * curH * curW;
-        o.flops = 2.0 * M * ((double)cm * c4 + (stop != 1 ? 9.0 * cm * cm : 0.0) + (stop == 0 ? (double)c4 * cm : 0.0));
-        o.bytes = (M * c4 + M * o.Co + (double)cm * c4 + (stop != 1 ? 9.0 * cm * cm : 0.0) + (stop == 0 ? (double)c4 * cm : 0.0)) * eb;
-        P.ops.push_back(o);
-        int out = o.out_buf;
-        if (stop == 1) {                               // tests: the unfused conv2 and conv3 follow the fused conv1
-          const int t2 = add_conv((int)ui + 1, out, curH, curW, cm, -1, &h2, &w2);
-          release(out);
-          out = add_conv((int)ui + 2, t2, h2, w2, cm, cur, &h3, &w3);
-          release(t2);
-        } else if (stop == 2) {
-          const int t2 = out;
-          out = add_conv((int)ui + 2, t2, curH, curW, cm, cur, &h3, &w3);
-          release(t2);
-        }
-        release(cur);
-        cur = out;
-        ui += 3;
-        continue;
-      }
-    }
     const int t1 = add_conv((int)ui, cur, curH, curW, curC, -1, &h1, &w1);
     const int t2 = add_conv((int)ui + 1, t1, h1, w1, units[ui].cout, -1, &h2, &w2);
     release(t1);
@@ -330,21 +256,19 @@ int ensure_buffers(nbc_ctx* c) {
   return NBC_OK;
 }
 
-// One convolution launch of the plan (shared by nbc_forward and nbc_autotune): N images, the first of which is
-// image img0 of the whole-batch buffers (sub-batched tail; 0 otherwise).
-int launch_conv_op(nbc_ctx* c, const Op& o, int N, int img0, int tile, hipStream_t s, hipError_t* err) {
+// One convolution launch of the plan (shared by nbc_forward and nbc_autotune).
+int launch_conv_op(nbc_ctx* c, const Op& o, int N, int tile, hipStream_t s, hipError_t* err) {
   const auto& units = conv_units();
   const ConvUnit& u = units[o.unit];
   const PackedConv& pc = c->layout.convs[o.unit];
   const int prec = c->precision;
   const size_t eb = elem_bytes(prec);
   ConvArgs a{};
-  a.x = static_cast<const unsigned char*>(c->bufs[o.in_buf]) + (o.in_full ? (size_t)img0 * o.Hi * o.Wi * o.Ci * eb : 0);
+  a.x = c->bufs[o.in_buf];
   a.w = c->weights + pc.w_off;
   a.scale = reinterpret_cast<const float*>(c->weights + pc.scale_off);
   a.shift = reinterpret_cast<const float*>(c->weights + pc.shift_off);
-  a.res = o.res_buf >= 0 ? static_cast<const unsigned char*>(c->bufs[o.res_buf]) + (o.res_full ? (size_t)img0 * o.Ho * o.Wo * o.Co * eb : 0)
-                          : nullptr;
+  a.res = o.res_buf >= 0 ? c->bufs[o.res_buf] : nullptr;
   a.y = c->bufs[o.out_buf];
   a.N = N; a.Hi = o.Hi; a.Wi = o.Wi; a.Ci = o.Ci;
   a.Ho = o.Ho; a.Wo = o.Wo; a.Co = o.Co;
@@ -376,7 +300,6 @@ const char* kernel_name(OpKind k) {
     case OP_CONV: return "conv_dma";
     case OP_MAXPOOL: return "maxpool";
     case OP_HEAD1X1: return "head1x1";
-    case OP_BOTTLENECK: return "bottleneck_x2";
     default: return "upsample_argmax";
   }
 }
@@ -525,28 +448,6 @@ int nbc_set_keep_activations(nbc_ctx* c, int on) {
   return NBC_OK;
 }
 
-int nbc_set_sub_batch(nbc_ctx* c, const char* first_op, int images) {
-  if (!c) return set_error(NBC_ERR_INVALID, "null context");
-  std::string name = first_op && images >= 1 ? first_op : "";
-  if (!name.empty()) {
-    bool ok = false;
-    for (const ConvUnit& u : conv_units())
-      if (name == u.name && (u.block_first || name == "classifier.0")) ok = true;
-    if (!ok) return set_error(NBC_ERR_INVALID, "nbc_set_sub_batch: '" + name + "' is not the first convolution of a bottleneck, nor classifier.0");
-  }
-  c->sub_first = name;
-  c->sub_n = name.empty() ? 0 : images;
-  return NBC_OK;                                     // the next nbc_forward / nbc_reserve plans accordingly
-}
-
-int nbc_set_fusion(nbc_ctx* c, int mask, int stop_after) {
-  if (!c) return set_error(NBC_ERR_INVALID, "null context");
-  if (mask < -1 || mask > 0x1f || stop_after < 0 || stop_after > 2) return set_error(NBC_ERR_INVALID, "nbc_set_fusion: mask -1 .. 31, stop_after 0 .. 2");
-  c->fuse_mask = mask;
-  c->fuse_stop = stop_after;
-  return NBC_OK;                                     // the next nbc_forward / nbc_reserve plans accordingly
-}
-
 int nbc_nonfinite_seen(nbc_ctx* c, int reset) {
   if (!c) return set_error(NBC_ERR_INVALID, "null context");
   if (!c->nonfinite) return 0;                       // no forward yet
@@ -556,6 +457,14 @@ int nbc_nonfinite_seen(nbc_ctx* c, int reset) {
   NBC_HIP(hipMemcpy(&v, c->nonfinite, sizeof(v), hipMemcpyDeviceToHost));
   if (reset && v) NBC_HIP(hipMemset(c->nonfinite, 0, sizeof(v)));
   return v ? 1 : 0;
+}
+
+int nbc_nonfinite_peek_async(nbc_ctx* c, uint32_t* host_dst, void* hip_stream) {
+  if (!c || !host_dst) return set_error(NBC_ERR_INVALID, "nbc_nonfinite_peek_async: null argument");
+  if (!c->nonfinite) { *host_dst = 0; return NBC_OK; }   // no forward yet
+  NBC_HIP(hipSetDevice(c->device));
+  NBC_HIP(hipMemcpyAsync(host_dst, c->nonfinite, sizeof(uint32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
+  return NBC_OK;
 }
 
 int nbc_set_profiling(nbc_ctx* c, int on) {
@@ -601,27 +510,11 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
   }
 
   const size_t nops = P.ops.size();
-  // launch list: (op, first image, images).  Without a sub-batched tail every op runs once on the whole batch;
-  // with one, ops [sub_from, upsample) run depth-first on sub_n images at a time.
-  struct Launch { int op, img0, nb; };
-  std::vector<Launch> launches;
-  launches.reserve(nops);
-  {
-    const int tail0 = P.sub_from >= 0 ? P.sub_from : (int)nops;
-    int tail1 = (int)nops;
-    for (size_t i = 0; i < nops; ++i)
-      if (P.ops[i].kind == OP_UPSAMPLE) tail1 = (int)i;
-    for (int i = 0; i < tail0; ++i) launches.push_back({i, 0, N});
-    if (P.sub_from >= 0)
-      for (int img0 = 0; img0 < N; img0 += P.sub_n)
-        for (int i = tail0; i < tail1; ++i) launches.push_back({i, img0, std::min(P.sub_n, N - img0)});
-    for (int i = P.sub_from >= 0 ? tail1 : tail0; i < (int)nops; ++i) launches.push_back({i, 0, N});
-  }
-  const size_t nl = launches.size();
+  const size_t nl = nops;                              // one launch per op
   constexpr size_t kMaxProfSets = 4096;
   std::vector<hipEvent_t>* evs = nullptr;
   if (c->profiling && c->prof_used < kMaxProfSets) {
-    if (c->prof_used > 0 && (c->prof_ops.size() != nops || c->prof_launch_op.size() != nl)) c->prof_used = 0;   // plan changed: restart
+    if (c->prof_used > 0 && c->prof_ops.size() != nops) c->prof_used = 0;   // plan changed: restart
     if (c->prof_sets.size() <= c->prof_used) c->prof_sets.emplace_back();
     evs = &c->prof_sets[c->prof_used];
     while (evs->size() < nl + 1) {
@@ -630,15 +523,12 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
       evs->push_back(ev);
     }
     c->prof_ops = P.ops;
-    c->prof_launch_op.resize(nl);
-    for (size_t l = 0; l < nl; ++l) c->prof_launch_op[l] = launches[l].op;
   }
   float* lowres = logits_lowres_dev ? logits_lowres_dev : c->lowres;
 
   if (evs) NBC_HIP(hipEventRecord((*evs)[0], s));
   for (size_t l = 0; l < nl; ++l) {
-    const Op& o = P.ops[launches[l].op];
-    const int img0 = launches[l].img0, nb = launches[l].nb;
+    const Op& o = P.ops[l];
     hipError_t e = hipSuccess;
     int rc = NBC_OK;
     switch (o.kind) {
@@ -651,43 +541,21 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
       case OP_CONV: {
         int tile = c->conv_tile;
         if (!conv_tile_ok(prec, tile, o.Co)) tile = o.tile;   // no override, or it does not fit: planned tile
-        rc = launch_conv_op(c, o, nb, img0, tile, s, &e);
+        rc = launch_conv_op(c, o, N, tile, s, &e);
         if (rc != NBC_OK) return rc;
         break;
       }
       case OP_MAXPOOL:
         e = launch_maxpool3x3s2(c->bufs[o.in_buf], c->bufs[o.out_buf], N, o.Hi, o.Wi, o.Ci, o.Ho, o.Wo, prec, s);
         break;
-      case OP_BOTTLENECK: {
-        const auto& units = conv_units();
-        const PackedConv &p1 = c->layout.convs[o.unit], &p2 = c->layout.convs[o.unit + 1], &p3 = c->layout.convs[o.unit + 2];
-        const int cm = units[o.unit].cout;
-        const size_t xb = (size_t)nb * o.Hi * o.Wi * o.Ci * 4;
-        if (xb >= 0x80000000ull) return set_error(NBC_ERR_INVALID, "activation of " + o.name + " exceeds 2 GiB: lower the batch size");
-        BottleneckArgs a{};
-        a.x = static_cast<const unsigned char*>(c->bufs[o.in_buf]) + (o.in_full ? (size_t)img0 * o.Hi * o.Wi * o.Ci * 4 : 0);
-        a.out = o.stop_after ? nullptr : c->bufs[o.out_buf];
-        a.dbg = o.stop_after ? c->bufs[o.out_buf] : nullptr;
-        a.w1 = c->weights + p1.w_off; a.w2 = c->weights + p2.w_off; a.w3 = c->weights + p3.w_off;
-        a.s1 = reinterpret_cast<const float*>(c->weights + p1.scale_off); a.b1 = reinterpret_cast<const float*>(c->weights + p1.shift_off);
-        a.s2 = reinterpret_cast<const float*>(c->weights + p2.scale_off); a.b2 = reinterpret_cast<const float*>(c->weights + p2.shift_off);
-        a.s3 = reinterpret_cast<const float*>(c->weights + p3.scale_off); a.b3 = reinterpret_cast<const float*>(c->weights + p3.shift_off);
-        a.x_bytes = (unsigned)xb;
-        a.w1_bytes = (unsigned)((size_t)cm * p1.ksteps * kKStepBytes);
-        a.w2_bytes = (unsigned)((size_t)cm * p2.ksteps * kKStepBytes);
-        a.w3_bytes = (unsigned)((size_t)4 * cm * p3.ksteps * kKStepBytes);
-        a.N = nb; a.H = o.Hi; a.W = o.Wi; a.stop_after = o.stop_after;
-        e = launch_bottleneck_x2(a, cm, s);
-        break;
-      }
       case OP_HEAD1X1: {
         const PackedConv& pc = c->layout.convs[o.unit];
         if (o.Ci != 512) return set_error(NBC_ERR_STATE, "classifier.4 expects 512 input channels");
         // also clears this launch's share of the counters (3 per image) when the batch has at most 256 of them
-        unsigned long long* cz = counts_dev && 3 * N <= 256 ? reinterpret_cast<unsigned long long*>(counts_dev) + 3 * img0 : nullptr;
+        unsigned long long* cz = counts_dev && 3 * N <= 256 ? reinterpret_cast<unsigned long long*>(counts_dev) : nullptr;
         e = launch_head1x1(c->bufs[o.in_buf], reinterpret_cast<const float*>(c->weights + pc.w_off),
                            reinterpret_cast<const float*>(c->weights + pc.shift_off),
-                           lowres + (size_t)img0 * kNumClasses * o.Ho * o.Wo, nb, o.Ho * o.Wo, prec, cz, c->nonfinite, s);
+                           lowres, N, o.Ho * o.Wo, prec, cz, c->nonfinite, s);
         break;
       }
       case OP_UPSAMPLE:
@@ -716,28 +584,23 @@ static int collect_profile(nbc_ctx* c) {
   if (c->prof_used == 0) return NBC_OK;
   const auto& units = conv_units();
   const size_t nops = c->prof_ops.size();
-  const size_t nl = c->prof_launch_op.size();
-  NBC_HIP(hipEventSynchronize(c->prof_sets[c->prof_used - 1][nl]));
+  NBC_HIP(hipEventSynchronize(c->prof_sets[c->prof_used - 1][nops]));
   c->records.assign(nops, nbc_op_record{});
   std::vector<double> sum(nops, 0.0);
-  std::vector<int> per_forward(nops, 0);
-  for (size_t l = 0; l < nl; ++l) {
-    const int i = c->prof_launch_op[l];
-    ++per_forward[i];
+  for (size_t i = 0; i < nops; ++i)
     for (size_t k = 0; k < c->prof_used; ++k) {
       float ms = 0.f;
-      NBC_HIP(hipEventElapsedTime(&ms, c->prof_sets[k][l], c->prof_sets[k][l + 1]));
+      NBC_HIP(hipEventElapsedTime(&ms, c->prof_sets[k][i], c->prof_sets[k][i + 1]));
       sum[i] += ms;
     }
-  }
   for (size_t i = 0; i < nops; ++i) {
     const Op& o = c->prof_ops[i];
     nbc_op_record& r = c->records[i];
     std::snprintf(r.name, sizeof(r.name), "%s", o.name.c_str());
     std::snprintf(r.kernel, sizeof(r.kernel), "%s", kernel_name(o.kind));
-    r.ms = (float)(sum[i] / (double)c->prof_used);     // per forward: all sub-batch launches of the op together
+    r.ms = (float)(sum[i] / (double)c->prof_used);
     r.calls = (int32_t)c->prof_used;
-    r.launches = per_forward[i];
+    r.launches = 1;
     r.flops = o.flops;
     r.bytes = o.bytes;
     r.kh = r.kw = (o.kind == OP_CONV || o.kind == OP_HEAD1X1) ? units[o.unit].k : 0;
@@ -765,16 +628,16 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
   for (size_t oi = 0; oi < P.ops.size(); ++oi) {
     Op& o = P.ops[oi];
     if (o.kind != OP_CONV) continue;
-    const int NB = P.sub_from >= 0 && (int)oi >= P.sub_from ? P.sub_n : N;   // images per launch of this op
+    const int NB = N;
     float best_ms = 1e30f;
     int best = o.tile;
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
       if (!conv_tile_ok(c->precision, tile, o.Co)) continue;
       hipError_t e = hipSuccess;
-      rc = launch_conv_op(c, o, NB, 0, tile, s, &e);                      // warm-up (and attribute set-up)
+      rc = launch_conv_op(c, o, NB, tile, s, &e);                         // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
       (void)hipEventRecord(e0, s);
-      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, NB, 0, tile, s, &e);
+      for (int k = 0; k < reps; ++k) (void)launch_conv_op(c, o, NB, tile, s, &e);
       (void)hipEventRecord(e1, s);
       if (hipEventSynchronize(e1) != hipSuccess) continue;
       float ms = 0.f;

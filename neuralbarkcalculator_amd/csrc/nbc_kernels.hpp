@@ -41,20 +41,6 @@ bool conv_tile_ok(int precision, int tile, int Co);   // the tile exists for the
 int choose_conv_tile(int M, int Co, int K, int precision);   // K = Cin*kh*kw; the default tile of a layer (cost model)
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
 
-// A whole bottleneck without downsample in ONE launch, f16x2 mode (bottleneck_fused.hip): out = relu(bn3(conv3(relu(
-// bn2(conv2(relu(bn1(conv1(x)))))))) + x), bit-identical to the three conv launches.  x, out: [N][H][W][4*cmid] f16x2.
-struct BottleneckArgs {
-  const void* x;
-  void* out;
-  const void *w1, *w2, *w3;            // packed rows of conv1 [cmid][4*cmid], conv2 [cmid][3][3][cmid], conv3 [4*cmid][cmid]
-  const float *s1, *b1, *s2, *b2, *s3, *b3;
-  unsigned x_bytes, w1_bytes, w2_bytes, w3_bytes;
-  int N, H, W;
-  int stop_after;                      // 0: the whole bottleneck; 1 / 2 (tests): stop behind conv1 / conv2 and write t1 / t2 to dbg
-  void* dbg;                           // [N][H][W][cmid] f16x2 when stop_after != 0
-};
-hipError_t launch_bottleneck_x2(const BottleneckArgs& a, int cmid, hipStream_t s);   // cmid 64 (layer1) or 128 (layer2)
-
 // float32 NCHW [N,3,H,W] -> NHWC elements padded to 16 bytes per pixel.
 hipError_t launch_ingest_f32(const float* x, void* y, int N, int H, int W, int precision, hipStream_t s);
 // uint8 NHWC [N,H,W,3] -> same, applying (u8/255 - mean)/std in f32 (dataset.py:175-186).

@@ -228,6 +228,23 @@ static void split_groups(float* data, size_t nfloats, int group) {
   }
 }
 
+// The power of two k that nbc_pack_weights multiplies a weight row by in f16x2 mode: largest finite |w| * 2^k in [1, 2).
+// 0 for a row of zeros (or of nothing finite).  Clamped to +-66 so that the BatchNorm scale the inverse is folded into
+// stays a normal f32 for any gamma / sqrt(var + eps) between 2^-60 and 2^60; a row beyond the clamp (largest weight below
+// 2^-67 or above 2^67) is moved by 2^+-66 and keeps the rest of its exponent.
+int f16x2_row_exponent(const float* row, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) {
+    const float a = std::fabs(row[i]);
+    if (std::isfinite(a) && a > m) m = a;
+  }
+  if (m == 0.f) return 0;
+  int e = 0;
+  (void)std::frexp(m, &e);                            // m = f * 2^e, f in [0.5, 1)
+  const int k = 1 - e;                                // m * 2^k in [1, 2)
+  return k > 66 ? 66 : (k < -66 ? -66 : k);
+}
+
 thread_local std::string g_last_error;
 
 int set_error(int code, const std::string& msg) {
@@ -348,8 +365,25 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
             else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
           }
     }
-    if (precision == NBC_PREC_F16X2)   // element e of a row in its f32-sized slot -> 32-element groups [h0 x 32][h1 x 32] (stem: taps of 4)
+    // f16x2: a convolution in front of a BatchNorm is scale-free, so a checkpoint may hold weight rows of any magnitude,
+    // and f16 pieces cannot: below 2.4e-4 the low piece is an f16 subnormal (the split keeps fewer and fewer bits, with
+    // finite results and no flag), beyond 65504 the high piece is infinite.  Every output channel's row is therefore
+    // multiplied by the power of two that puts its largest |w| into [1, 2) before the split -- exact -- and the f32
+    // BatchNorm scale of that channel by the inverse power below -- exact as well: the epilogue's fma(acc, scale, shift)
+    // sees 2^k acc * 2^-k scale.  What stays is relative to the row: a weight below 2^-13 of its row's largest loses low
+    // bits, an absolute error of 2^-36 of that largest weight.
+    std::vector<int> row_exp(precision == NBC_PREC_F16X2 ? c.cout : 0, 0);
+    if (precision == NBC_PREC_F16X2) {
+      const size_t row_floats = row_bytes / 4;
+      for (int o = 0; o < c.cout; ++o) {
+        float* row = reinterpret_cast<float*>(base + p.w_off + (size_t)o * row_bytes);
+        row_exp[o] = f16x2_row_exponent(row, row_floats);
+        if (row_exp[o] != 0)
+          for (size_t e = 0; e < row_floats; ++e) row[e] = std::ldexp(row[e], row_exp[o]);
+      }
+      // element e of a row in its f32-sized slot -> 32-element groups [h0 x 32][h1 x 32] (stem: taps of 4)
       split_groups(reinterpret_cast<float*>(base + p.w_off), (size_t)c.cout * row_bytes / 4, p.stem ? 4 : 32);
+    }
     // eval-mode BatchNorm as ATen applies it: alpha = gamma * invstd, beta = bias - mean * alpha
     const float* g = static_cast<const float*>(given[c.bn + ".weight"]->data);
     const float* b = static_cast<const float*>(given[c.bn + ".bias"]->data);
@@ -361,7 +395,9 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
       const float invstd = 1.0f / std::sqrt(var[o] + kBnEps);
       const float alpha = g[o] * invstd;
       const float t = mu[o] * alpha;
-      scale[o] = alpha;
+      // f16x2: the row's power of two comes off again here (exact unless alpha * 2^-k leaves f32's normal range, which
+      // f16x2_row_exponent's clamp keeps 2^40 away from for any alpha between 2^-60 and 2^60)
+      scale[o] = row_exp.empty() ? alpha : std::ldexp(alpha, -row_exp[o]);
       shift[o] = b[o] - t;
     }
   }

@@ -308,16 +308,15 @@ class FCNResNet50:
             _lib.check(rc, "nbc_nonfinite_seen")
         return rc == 1
 
-    def set_fusion(self, mask: int = -1, stop_after: int = 0):
-        """f16x2: which of the five bottlenecks without downsample of layer1 / layer2 run as one fused launch (bits 0..4;
-        -1 = the library's default, 0 = none); stop_after 1 / 2 (tests) ends the fused launch behind conv1 / conv2."""
-        _lib.check(self._lib.nbc_set_fusion(self._require_ctx(), int(mask), int(stop_after)), "nbc_set_fusion")
-
-    def set_sub_batch(self, first_op=None, images: int = 0):
-        """Run everything from conv unit `first_op` (the first convolution of a bottleneck, or "classifier.0") to
-        classifier.4 depth-first on `images` images at a time (nbc_set_sub_batch); None / 0 = whole-batch plan."""
-        name = first_op.encode() if first_op and images >= 1 else None
-        _lib.check(self._lib.nbc_set_sub_batch(self._require_ctx(), name, int(images)), "nbc_set_sub_batch")
+    def nonfinite_peek_async(self, host_word: torch.Tensor):
+        """Enqueue, on the current stream, a copy of the sticky non-finite word into ``host_word`` (pinned int32 [1]); no
+        synchronisation (nbc_nonfinite_peek_async).  Non-zero once the stream has caught up = a forward of this context
+        ahead of the copy produced a NaN / infinite logit."""
+        if host_word.dtype != torch.int32 or host_word.numel() != 1 or host_word.is_cuda or not host_word.is_pinned():
+            raise ValueError("host_word must be a pinned int32 CPU tensor with one element")
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.nbc_nonfinite_peek_async(self._require_ctx(), host_word.data_ptr(), stream), "nbc_nonfinite_peek_async")
 
     def set_conv_tile(self, tile: int = -1):
         """Tuning/test knob: tile -1 = per-layer choice,

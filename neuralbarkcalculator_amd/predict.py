@@ -487,11 +487,15 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         prof["pool.decode"] += t1 - t0; prof["pool.preprocess"] += t2 - t1; prof["pool.write_processed"] += t3 - t2
         return out
 
+    label_paths = []                                 # label PNGs this rank has written (removed again if the run turns out invalid)
+
     def finish(k, gi, lab, c1, c2):
         """Pool: label PNG (models.py:349-356) + the image's row."""
         d = items[gi]
         t0 = clock()
-        write_png(os.path.join(root, "results", "outputs", d["wood"], d["name"]), label_png(lab), lvl_lab)
+        path = os.path.join(root, "results", "outputs", d["wood"], d["name"])
+        label_paths.append(path)
+        write_png(path, label_png(lab), lvl_lab)
         rows[k] = (gi, lab.shape[0], lab.shape[1], c1, c2)
         prof["pool.write_labels"] += clock() - t0
 
@@ -503,6 +507,10 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     ring = [(torch.empty(full, dtype=torch.uint8).pin_memory(), torch.empty((batch, 3), dtype=torch.int64).pin_memory())
             for _ in range(depth)]
     ring_ev = [torch.cuda.Event() for _ in range(depth)]
+    # f16x2: the context's sticky non-finite word rides back with every batch (nbc_nonfinite_peek_async: no synchronisation)
+    flag_host = torch.zeros(depth, dtype=torch.int32).pin_memory()
+    check_flag = precision == "f16x2"
+    bad_seen = [False]
     stage = [{"buf": torch.empty(full * 3, dtype=torch.uint8).pin_memory(), "ev": torch.cuda.Event()} for _ in range(depth)]
     pending = deque()                                # (slot, [(k, gi)], n, h, w), oldest first
     done = []
@@ -513,6 +521,9 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     def consume(p):
         slot, members, n, h, w = p
         ring_ev[slot].synchronize()
+        if check_flag and int(flag_host[slot]) != 0:
+            bad_seen[0] = True                       # this batch's labels (and every later one's) are not valid: nothing is written
+            return
         lab_host, cnt_host = ring[slot]
         labs = lab_host[: n * h * w].numpy().reshape(n, h, w).copy()
         cnts = cnt_host[:n].numpy().copy()
@@ -529,6 +540,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         futs = {k: pool.submit(prepare, mine[k]) for k in (windows[0] if windows else [])}
         t_loop = time.perf_counter()
         for wi, win in enumerate(windows):
+            if bad_seen[0]:                              # f16x2 cannot carry these weights: the run is abandoned here
+                break
             if wi + 1 < len(windows):                    # the pool starts on the next window before the GPU gets this one
                 for k in windows[wi + 1]:
                     futs[k] = pool.submit(prepare, mine[k])
@@ -541,6 +554,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
             for shape, ks in sorted(groups.items()):
                 shape_count[shape] += len(ks)
                 for a in range(0, len(ks), batch):
+                    if bad_seen[0]:
+                        break
                     part = ks[a:a + batch]
                     n, (h, w) = len(part), shape[:2]
                     t0 = clock()
@@ -570,6 +585,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
                                                             small_zones=small_zones)   # models.py:269-276 on the device
                         ring[slot][0][:need].copy_(labels.reshape(-1), non_blocking=True)
                         ring[slot][1][:n].copy_(counts, non_blocking=True)
+                        if check_flag:
+                            mdl.nonfinite_peek_async(flag_host[slot:slot + 1])
                         ring_ev[slot].record()
                     t2 = clock()
                     pending.append((slot, [(k, mine[k]) for k in part], n, h, w))
@@ -591,14 +608,24 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         # f16x2 keeps every value as two f16 pieces: an activation beyond +-65504 cannot be represented and turns into NaN
         # (never into a silently wrong number).  Unknown weights that do this belong in the f32 MFMA mode.  Every rank
         # learns of it (one more tiny collective) so that all of them leave before the row gather, none waits in it.
-        bad = any(m.nonfinite_seen() for m in models)
+        # The word rides back with every batch (consume), so a rank that sees it stops at that batch instead of finishing its
+        # shard; the contexts are all read (and reset) here once more, whatever the first one says.
+        bad = any([m.nonfinite_seen() for m in models]) or bad_seen[0]
         if dist is not None:
             flag = torch.tensor([int(bad)], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             bad = bool(int(flag.item()))
         if bad:
-            raise NonFiniteLogits("a forward produced non-finite logits in f16x2 mode (an activation beyond f16's range, or NaN/inf "
-                                  "in the weights): the label PNGs of this run are not valid; rerun with --precision fp32")
+            for path in label_paths:                 # this rank's label PNGs of the invalid run: a crash before the rerun
+                try:                                 # must not leave them behind (the processed/ images do not depend on
+                    os.remove(path)                  # the arithmetic and stay)
+                except OSError:
+                    pass
+            err = NonFiniteLogits("a forward produced non-finite logits in f16x2 mode (an activation beyond f16's range, or NaN/inf "
+                                  "in the weights): the run was abandoned after %d of this rank's %d images and its label PNGs "
+                                  "removed; rerun with --precision fp32" % (min(n_batches * batch, len(mine)), len(mine)))
+            err.batches_run, err.images_this_rank = n_batches, len(mine)
+            raise err
 
     if os.environ.get("NBC_FOLDER_PROFILE"):
         print("rank %d stage seconds (pool stages summed over %d threads): %s; loop wall %.2f s" %
@@ -674,11 +701,19 @@ def main(argv=None):
         idx = int(args.device.split(":")[1])
     kw = dict(batch=args.batch, autotune=args.autotune, streams=args.streams)
     if args.precision == "auto":
+        stats = None
         try:
             stats = predict_folder(args.root_path, args.model_path, "f16x2", args.exclude_nodes, not args.no_small_zones, idx, **kw)
         except NonFiniteLogits as e:                 # raised on every rank alike
             if int(os.environ.get("RANK", "0")) == 0:
                 print("predict: %s -- running the folder again on the f32 MFMA" % e, flush=True)
+        if stats is None:
+            # outside the except block: the exception's traceback holds the first run's frame (four model contexts with
+            # their workspaces, the pinned rings, the streams) for as long as the block lasts
+            import gc
+            import torch
+            gc.collect()
+            torch.cuda.empty_cache()
             stats = predict_folder(args.root_path, args.model_path, "fp32", args.exclude_nodes, not args.no_small_zones, idx, **kw)
     else:
         stats = predict_folder(args.root_path, args.model_path, args.precision, args.exclude_nodes,

@@ -17,10 +17,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "perf: compares timings (needs a GPU; never part of -m gpu: run with -m perf)")
 
 
+def marker_expression_asks_for_perf(expr: str) -> bool:
+    """True when the -m expression selects a test BECAUSE it is marked `perf`: it accepts an item marked {gpu, perf}
+    and rejects the same item without the perf marker.  `-m perf` and `-m "gpu and perf"` do; `-m gpu`,
+    `-m "gpu and not perf"`, `-m "not perf"` and a marker that merely contains the letters (`perfect`) do not."""
+    if not expr.strip():
+        return False
+    from _pytest.mark.expression import Expression
+    try:
+        e = Expression.compile(expr)
+    except Exception:
+        return False
+    with_perf = e.evaluate(lambda name, **kw: name in ("gpu", "perf"))
+    without = e.evaluate(lambda name, **kw: name == "gpu")
+    return bool(with_perf and not without)
+
+
 def pytest_collection_modifyitems(config, items):
-    """A test marked `perf` asserts on measured durations: it runs only when the marker expression names it, so a
+    """A test marked `perf` asserts on measured durations: it runs only when the marker expression asks for it, so a
     noisy box cannot turn the correctness suite (-m gpu) red."""
-    if "perf" in (config.getoption("-m") or ""):
+    if marker_expression_asks_for_perf(config.getoption("-m") or ""):
         return
     skip = pytest.mark.skip(reason="timing comparison: run with -m perf")
     for item in items:

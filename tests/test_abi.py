@@ -169,7 +169,13 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
             want[:, slot * cin_pad: slot * cin_pad + u.cin] = khkwci[:, tap // u.k, tap % u.k, :]
         if prec == 1:
             want = torch.from_numpy(want).to(torch.bfloat16).float().numpy()   # RNE like the packer
+        row_pow2 = np.ones(u.cout, np.float32)
         if prec == 2:
+            # every output channel's row is normalised by the power of two that puts its largest |w| into [1, 2)
+            # (exact), split, and the inverse goes into that channel's BatchNorm scale below
+            row_pow2 = _row_pow2(want)
+            want = want * row_pow2[:, None]
+            assert (np.abs(want).max(1) >= 1).all() and (np.abs(want).max(1) < 2).all()
             w0 = want.astype(np.float16).astype(np.float32)
             np.testing.assert_array_equal(g0, w0, err_msg=u.name)
             np.testing.assert_array_equal(g1, ((want - w0) * np.float32(2048)).astype(np.float16).astype(np.float32), err_msg=u.name)
@@ -183,9 +189,52 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
         g, b = sd_np[u.bn + ".weight"], sd_np[u.bn + ".bias"]
         mu, var = sd_np[u.bn + ".running_mean"], sd_np[u.bn + ".running_var"]
         inv = np.float32(1.0) / np.sqrt(var + np.float32(1e-5), dtype=np.float32)
-        np.testing.assert_array_equal(scale, g * inv)
+        np.testing.assert_array_equal(scale, g * inv / row_pow2)            # a power of two: the division is exact
         np.testing.assert_array_equal(shift, b - mu * (g * inv))
     assert off == blob.nbytes
+
+
+def _row_pow2(rows):
+    """2^k per row with max |w| * 2^k in [1, 2) (1 for a row of zeros): what nbc_pack_weights normalises f16x2 rows by."""
+    m = np.abs(rows).max(1).astype(np.float64)
+    k = np.where(m > 0, -np.floor(np.log2(np.where(m > 0, m, 1.0))), 0.0)
+    return np.exp2(k).astype(np.float32)
+
+
+@pytest.mark.parametrize("log2_scale", [-20, -16, -12, 0, 10, 30])
+def test_f16x2_weight_rows_are_normalised_before_the_split(built_lib, sd_np, log2_scale):
+    """The f16 pieces of a weight hold it to 2^-23 only while both are normal f16 numbers (|w| >= 2.4e-4 as it stands).
+    nbc_pack_weights multiplies every output channel's row by a power of two first (largest |w| into [1, 2)) and the
+    channel's f32 BatchNorm scale by the inverse, so a checkpoint whose convolution weights are 1e-6 (or 1e7) in
+    magnitude -- a convolution in front of a BatchNorm is scale-free -- packs to the same pieces as the same network at
+    ordinary magnitudes, and pieces * 2^-k give every weight back to 2^-23 of the row's largest."""
+    name, bn = "backbone.layer3.2.conv2", "backbone.layer3.2.bn2"
+    s = np.float32(2.0 ** log2_scale)
+    sd = dict(sd_np)
+    sd[name + ".weight"] = sd_np[name + ".weight"] * s
+    blob, ref = pack_state_dict(sd, "f16x2"), pack_state_dict(sd_np, "f16x2")
+    off = 0
+    for u in topology.conv_units():
+        if u.bn is None:
+            break
+        ksteps = 7 if u.cin == 3 else u.k * u.k * u.cin * 4 // 128
+        wbytes = u.cout * ksteps * 128
+        a = lambda v: (v + 255) // 256 * 256
+        s_off = a(off + wbytes)
+        if u.name == name:
+            np.testing.assert_array_equal(blob[off: off + wbytes], ref[off: off + wbytes])        # the same pieces
+            scale = blob[s_off: s_off + u.cout * 4].view(np.float32)
+            scale_ref = ref[s_off: s_off + u.cout * 4].view(np.float32)
+            np.testing.assert_array_equal(scale, scale_ref * s)                                    # the scale carries 2^-k
+            g0, g1 = _join_f16x2(blob[off: off + wbytes], ksteps * 32, 32)
+            w = sd[name + ".weight"].transpose(0, 2, 3, 1).reshape(u.cout, -1).astype(np.float64)
+            inv = np.float32(1.0) / np.sqrt(sd[bn + ".running_var"] + np.float32(1e-5), dtype=np.float32)
+            k = 1.0 / _row_pow2(w).astype(np.float64)                                              # 2^-k per row
+            np.testing.assert_array_equal(scale, (sd[bn + ".weight"] * inv) * k.astype(np.float32))
+            back = (g0.astype(np.float64) + g1.astype(np.float64) / 2048.0) * k[:, None]
+            err = np.abs(back - w).max(1) / np.abs(w).max(1)
+            assert err.max() <= 2.0 ** -23, err.max()
+        off = a(a(s_off + u.cout * 4) + u.cout * 4)
 
 
 def test_model_fails_loudly_without_gpu(built_lib, sd_np):

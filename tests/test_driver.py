@@ -289,3 +289,11 @@ def test_bmp_header_fuzz_never_crashes(tmp_path):
         if out is not None:
             off, w, rows, stride, _ = lay
             assert out.shape == (rows, w, 3) and off + stride * rows <= len(b)
+
+
+def test_perf_marker_gate():
+    """tests/conftest.py: timing tests run only when the -m expression asks for the perf marker itself."""
+    from conftest import marker_expression_asks_for_perf as asks
+    assert asks("perf") and asks("gpu and perf") and asks("perf and gpu")
+    for expr in ("", "gpu", "not gpu", "gpu and not perf", "not perf", "perfect", "gpu or perfect"):
+        assert not asks(expr), expr

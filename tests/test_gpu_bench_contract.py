@@ -29,6 +29,12 @@ def check_roofline(r, peak):
     assert abs(r["achieved"] - r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
     assert isinstance(r["traffic_note"], str)
+    # the rocprofv3 table's figure for the same kernel rides along whenever the committed table belongs to these kernel
+    # sources (the mechanism `traffic` uses); the raw-event frac reads a few percent under it
+    if r["traffic"] is not None:
+        assert r["table"].startswith("profiles/per_forward_ops_") and 0 < r["frac_rocprof_table"] < 1
+    else:
+        assert "frac_rocprof_table" not in r and "table" not in r
 
 
 def test_default_bench_line(built_lib):
@@ -42,6 +48,7 @@ def test_default_bench_line(built_lib):
     assert d["dtype"] == "f16x2" and "f32-grade" in d["dtype_note"] and d["data"] == "synthetic"
     assert d["config"]["workload"].startswith("configs[1]") and "model" not in d["config"]
     assert d["config"]["batch"] == 1 and d["config"]["precision"] == "f16x2"
+    assert d["config"]["frames"] == 100             # configs[1]: 100 synthetic frames, resident in HBM
     check_roofline(d["roofline"], 2500.0 / 3.0)
     assert d["roofline"]["mfma_flops_per_algorithmic_flop"] == 3
     c = d["cpu_baseline"]
@@ -50,7 +57,8 @@ def test_default_bench_line(built_lib):
     # the f32-grade modes: the label mask equals the oracle's but for exact logit ties (at most 4 per megapixel, the bound of
     # tests/test_gpu_parity.py), low-res logits within 5e-6 of the oracle's logit range
     for par, prec in ((d["parity"], "f16x2"), (d["f32_mfma_batch1"]["parity"], "fp32")):
-        assert par["precision"] == prec and par["label_mismatches"] <= 4 and par["pixels"] == 1024 * 1024
+        assert par["precision"] == prec and par["frames_compared"] == 4 and par["pixels"] == 4 * 1024 * 1024
+        assert max(par["per_frame_label_mismatches"]) <= 4
         assert par["max_oracle_margin_at_mismatch"] <= 1e-5 * par["oracle_logit_range"]
         assert par["max_lowres_logit_err_over_oracle_range"] <= 5e-6
     f = d["f32_mfma_batch1"]
@@ -63,14 +71,14 @@ def test_default_bench_line(built_lib):
     assert b["value"] > 0 and abs(b["value"] - 8e3 / b["ms_per_step"]) < 1e-6 * b["value"]
     check_roofline(b["roofline"], 2500.0)
     assert b["parity"]["precision"] == "bf16" and b["parity"]["label_match"] > 0.98
-    assert b["parity"]["pixels"] == 2 * 1024 * 1024
+    assert b["parity"]["pixels"] == 8 * 1024 * 1024 and b["parity"]["frames_compared"] == 8
 
 
 def test_bench_starts_its_own_ranks(built_lib):
     """`bench.py --gpus 2` with no torchrun environment starts two ranks itself (here both on cuda:0 over
     gloo: a one-GPU box) and prints one line for the two-rank job: weight broadcast, sharded frames,
     max-over-ranks timing, the row gather."""
-    d = run_bench("--gpus", "2", "--share-gpu", "--steps", "4", "--warmup", "1", "--no-bf16-leg")
+    d = run_bench("--gpus", "2", "--share-gpu", "--steps", "4", "--warmup", "1", "--no-bf16-leg", "--frames", "4")
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo"
     assert d["steps"] == 4 and abs(d["value"] - 2 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
     assert d["setup"]["weight_broadcast_s"] > 0 and d["setup"]["process_group_init_s"] > 0

@@ -313,9 +313,33 @@ def test_cli_falls_back_to_fp32_when_f16x2_overflows(tmp_path, sd_np, built_lib)
     assert "running the folder again on the f32 MFMA" in p.stdout and "predicted 2 images" in p.stdout
     with pytest.raises(drv.NonFiniteLogits):
         drv.predict_folder(root_call, ckpt2, precision="f16x2", device_index=0)
+    # the invalid run leaves no label PNG behind (a crash before the fp32 rerun must not leave invalid masks without a
+    # CSV); what the preprocessor wrote does not depend on the arithmetic and stays
+    for wood, name in (("sapin", "a.png"), ("epinette_gelee", "c.png")):
+        assert not os.path.exists(os.path.join(root_call, "results", "outputs", wood, name))
+        assert os.path.exists(os.path.join(root_call, "processed", "samples", wood, name))
+    assert not os.path.exists(os.path.join(root_call, "results", "final_stats.csv"))
     drv.predict_folder(root_call, ckpt2, precision="fp32", device_index=0)
     assert open(os.path.join(root_cli, "results", "final_stats.csv")).read() == open(os.path.join(root_call, "results", "final_stats.csv")).read()
     for wood, name in (("sapin", "a.png"), ("epinette_gelee", "c.png")):
         a = np.asarray(Image.open(os.path.join(root_cli, "results", "outputs", wood, name)))
         b = np.asarray(Image.open(os.path.join(root_call, "results", "outputs", wood, name)))
         assert np.array_equal(a, b)
+
+
+def test_f16x2_overflow_abandons_the_folder_at_the_first_batches(tmp_path, sd_np, built_lib):
+    """The sticky non-finite word rides back with every batch's labels (nbc_nonfinite_peek_async), so a folder whose weights
+    f16x2 cannot carry is abandoned after the batches that were in flight when the first one came back -- not after the
+    last image (what's weak 5) -- and no label PNG of the run stays on disk."""
+    big = dict(sd_np)
+    big["backbone.bn1.weight"] = sd_np["backbone.bn1.weight"] * np.float32(3e4)
+    layout = [("sapin", "s%02d.bmp" % i, 40 + i, 64, 96) for i in range(24)]
+    root = str(tmp_path / "many")
+    ckpt, _ = _make_folder(root, big, layout)
+    with pytest.raises(drv.NonFiniteLogits) as e:
+        drv.predict_folder(root, ckpt, precision="f16x2", device_index=0, batch=1, streams=2, window=4)
+    assert e.value.images_this_rank == 24 and e.value.batches_run <= 8, e.value.batches_run    # two windows at most
+    out = os.path.join(root, "results", "outputs", "sapin")
+    assert not os.path.isdir(out) or os.listdir(out) == []
+    st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0, batch=1, streams=2, window=4)
+    assert st["images_total"] == 24 and len(os.listdir(out)) == 24
