@@ -49,13 +49,24 @@ enum {
 enum {
   NBC_PREC_FP32 = 0,  /* f32 activations/weights, v_mfma_f32_32x32x2_f32: the parity mode */
   NBC_PREC_BF16 = 1,  /* bf16 activations/weights, f32 accumulate + f32 BN epilogue: throughput mode */
-  NBC_PREC_F16X2 = 2  /* f32-grade on the 16-bit matrix pipe: every f32 value x is kept as two f16 pieces, h0 = f16(x) and
-                         h1 = f16((x - h0) * 2^11) (x = h0 + h1 * 2^-11 to 2^-24 relative: one f32 rounding), 4 bytes per
-                         element like f32; a product is h0*h0' + (h0*h1' + h1*h0') * 2^-11, three EXACT f16 products on
-                         v_mfma_f32_16x16x32_f16 summed in f32 in two levels like the f32 mode (the dropped h1*h1' is 2^-24
-                         relative).  Error against float64 at the level of NBC_PREC_FP32 (profiles/r03_split_probe_*.log),
-                         same tolerances in the tests.  Values beyond +-65504 (f16's range) turn into NaN, never into a
-                         silently wrong number; activations of a batch-normalised network are orders of magnitude below. */
+  NBC_PREC_F16X2 = 2  /* f32-grade on the 16-bit matrix pipe: every f32 value is kept as two f16 pieces, 4 bytes per element
+                         like f32.
+                         Activations: X0 = f16(x), X1 = f16((x - X0) * 2^11); x = X0 + X1 * 2^-11 to 2^-23 relative at
+                         worst (rms 4e-8: the f32 level) for |x| >= 2^-12 = 2.4e-4.  Below that X1 is an f16 subnormal
+                         and the error is ABSOLUTE, at most 2^-36 (1.5e-11): harmless in a sum next to values of ordinary
+                         size, and finite, so no flag reports it.  Beyond +-65504 (f16's range) a value turns into NaN,
+                         never into a silently wrong number (nbc_nonfinite_seen).
+                         Weights: nbc_pack_weights multiplies every output channel's row by the power of two that puts
+                         its largest |w| into [2^14, 2^15) -- exact -- splits it into P = f16(w 2^k), Q = f16(w 2^k - P)
+                         (to 2^-23 of the row's largest weight; a weight below 2^-15 of it loses low bits, an absolute
+                         error of 2^-39 of the largest) and folds 2^-k into the channel's f32 BatchNorm scale -- exact.
+                         The magnitude of a checkpoint's weights therefore does not matter (a convolution in front of a
+                         BatchNorm is scale-free): 1e-6 or 1e6 pack to the same pieces.
+                         A product is P*X0 + Q*X0 + (P*2^-11)*X1, three EXACT f16 products on v_mfma_f32_16x16x32_f16,
+                         summed in ONE f32 chain per 256 channels that joins a running f32 sum (two levels, like the f32
+                         mode); the dropped Q*X1 is 2^-22 relative at worst.  Error against float64 at the level of
+                         NBC_PREC_FP32 and below the CPU reference's own (profiles/r04_fp64_adjudication_*.json), same
+                         tolerances in the tests. */
 };
 
 /* Layout of the image handed to nbc_forward. */
@@ -112,10 +123,10 @@ int nbc_state_key(int index, const char** name, int64_t shape[4], int32_t* ndim,
 int nbc_lowres_size(int H, int W, int* h, int* w);
 
 /* ---- weights (host side; no GPU needed) ------------------------------------------------ */
-/* The two f16 pieces NBC_PREC_F16X2 keeps of each of n f32 values (host arithmetic, bit patterns of IEEE binary16):
- * h0 = f16(x) rounded to nearest even, h1 = f16((x - h0) * 2^11).  What nbc_pack_weights does to the weights in that
- * mode and what the kernels do to every activation; exported so that the conversion can be checked against another
- * implementation of binary16 rounding. */
+/* The two f16 pieces NBC_PREC_F16X2 keeps of each of n f32 ACTIVATION values (host arithmetic, bit patterns of IEEE
+ * binary16): h0 = f16(x) rounded to nearest even, h1 = f16((x - h0) * 2^11).  What the kernels do to every activation
+ * (nbc_pack_weights uses the same rounding on the normalised weight rows, with an unscaled low piece); exported so that
+ * the conversion can be checked against another implementation of binary16 rounding. */
 int nbc_split_f16x2(const float* x, size_t n, uint16_t* h0, uint16_t* h1);
 
 /* Size in bytes of the packed weight blob for a precision (same on every rank). */
@@ -200,11 +211,13 @@ int nbc_resize_cubic_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, floa
 int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_u8_dev, int32_t* row_lit_dev,
                       int out_h, int out_w, void* hip_stream);
 
-/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..15 = 128x64, 128x128,
- * 256x128, 256x256, 128x128 (4 stages), 128x256, 256x64, 128x64 (2 stages), 64x128, then the 8-wave
- * 128x128 and 128x64, the 16-wave 256x128 and (bf16) the 16-wave 256x256, the 8-wave 128x128 of 64x32 wave tiles and
- * (f16x2) the same and the 8-wave 128x64 with four loader waves each (pixels x channels), forced wherever the layer's
- * Cout and the precision allow it. */
+/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..17 (pixels x channels): 0 128x64,
+ * 1 128x128 (4 waves of 64x64, 2 stages, two blocks per CU), 2 256x128, 3 256x256 (bf16), 4 128x128 (4 stages), 5 128x256,
+ * 6 256x64, 7 128x64 (2 stages), 8 64x128, 9 / 10 the 8-wave 128x128 / 128x64, 11 the 16-wave 256x128, 12 the 16-wave
+ * 256x256 (bf16), 13 the 8-wave 128x128 of 64x32 wave tiles, and f16x2 only: 14 / 15 = 13 / 10 with four loader waves,
+ * 16 = 128x128 of four 64x64 waves + four loader waves, 17 = 13 with two stages (two blocks per CU).  f16x2 has no tile
+ * 2, 3, 4, 11, 12; f32 no 3, 12.  Forced wherever the layer's Cout and the precision allow it; where they do not, the
+ * planned tile runs. */
 int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
 
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real

@@ -123,7 +123,7 @@ constexpr int min_waves_per_simd(int prec, int wm, int wn, int mt, int nt, int s
 // and step in the MFMA waves' own instruction stream cost more than the arithmetic.
 constexpr int loader_waves(int var) { return var == 8 ? 4 : 0; }
 template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
-__global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? 3 : min_waves_per_simd(PREC, WM, WN, MT, NT, S)) void conv_dma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM * WN + loader_waves(VAR)) / 4 : min_waves_per_simd(PREC, WM, WN, MT, NT, S)) void conv_dma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EB = PREC == 1 ? 2 : 4;           // f16x2: two f16 pieces per element, the f32 mode's geometry
   constexpr bool X2 = (PREC == 2);
@@ -299,18 +299,22 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? 3 : 
   f32x16 acc[M16 ? 1 : NT][M16 ? 1 : MT];
   f32x16 accI[F32 ? NT : 1][F32 ? MT : 1];
   f32x4 acc16[M16 ? NT16 : 1][M16 ? MT16 : 1];
-  // f16x2 (NBC_PREC_F16X2, split16.hpp): a K-step is 32 channels, its LDS row [h0 x 32][h1 x 32].  Per 16x16 tile and
-  // K-step three v_mfma_f32_16x16x32_f16: W0.X0 into accI2 (a chain of FLUSH K-steps = 256 exact products, then added
-  // to acc16 and cleared: the f32 mode's two-level sum), W1.X0 and W0.X1 into accS2, which carries 2^11 and joins at
-  // the end (its own rounding errors weigh 2^-11).  The dropped W1.X1 is 2^-24 relative.
-  f32x4 accI2[X2 ? NT16 : 1][X2 ? MT16 : 1], accS2[X2 ? NT16 : 1][X2 ? MT16 : 1];
+  // f16x2 (NBC_PREC_F16X2, split16.hpp): a K-step is 32 channels, its LDS row [X0 x 32][X1 x 32] for a pixel (x = X0 +
+  // X1 2^-11) and [P x 32][Q x 32] for a normalised weight row (w 2^k = P + Q, nbc_net.cpp).  Per 16x16 tile and K-step
+  // three v_mfma_f32_16x16x32_f16, every product exact in f32, all into ONE chain accI2: P.X0, Q.X0 and (P 2^-11).X1 --
+  // the last operand formed in registers (v_pk_mul_f16 by a power of two: exact for P >= 2^-3, which the row
+  // normalisation gives every weight down to 2^-17 of its row's largest) -- so the three share a scale and the wave
+  // keeps TWO accumulator sets instead of three: a 64x64 wave tile fits.  After FLUSH K-steps (256 channels x 3
+  // products) the chain is added to the running sum acc16 and cleared: the f32 mode's two-level sum.  The dropped
+  // Q.X1 is 2^-22 relative at worst.
+  f32x4 accI2[X2 ? NT16 : 1][X2 ? MT16 : 1];
   if constexpr (X2) {
 #pragma unroll
     for (int j = 0; j < NT16; ++j)
 #pragma unroll
       for (int i = 0; i < MT16; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { accI2[j][i][e] = 0.f; accS2[j][i][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) accI2[j][i][e] = 0.f;
   }
   if constexpr (M16) {
 #pragma unroll
@@ -443,8 +447,10 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? 3 : 
           for (int e = 0; e < 4; ++e) accI2[n / MT16][n % MT16][e] = 0.f;
         }
       }
+      const f16x8 kLow = {kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH};
       if constexpr (!STEM) {
-        // lane (r16, q16) reads, of row r16 of every 16-row block, chunk q16 (h0 of channels 8*q16..) and chunk 4 + q16 (h1)
+        // lane (r16, q16) reads, of row r16 of every 16-row block, chunk q16 (high pieces of channels 8*q16..) and chunk
+        // 4 + q16 (their low pieces)
         uint4 p0[MT16], p1[MT16], w0[NT16], w1[NT16];
 #pragma unroll
         for (int i = 0; i < MT16; ++i) {
@@ -456,39 +462,40 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? 3 : 
           w0[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, q16));
           w1[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, 4 + q16));
         }
-        // product-major: two MFMAs on one accumulator are NTI instructions apart
+        // product-major: two MFMAs on one accumulator are NTI instructions apart; the scaled high pieces of a weight
+        // block are formed right in front of the block's third products (four v_pk_mul_f16)
 #pragma unroll
         for (int idx = 0; idx < 3 * NTI; ++idx) {
           const int prod = idx / NTI, n = idx % NTI, j = n / MT16, i = n % MT16;
           if (prod == 0)
             accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p0[i]), accI2[j][i], 0, 0, 0);
           else if (prod == 1)
-            accS2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1[j]), __builtin_bit_cast(f16x8, p0[i]), accS2[j][i], 0, 0, 0);
-          else
-            accS2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p1[i]), accS2[j][i], 0, 0, 0);
+            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1[j]), __builtin_bit_cast(f16x8, p0[i]), accI2[j][i], 0, 0, 0);
+          else {
+            if (i == 0) w0[j] = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, w0[j]) * kLow);      // P -> P 2^-11, in place
+            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p1[i]), accI2[j][i], 0, 0, 0);
+          }
           if (do_issue && (idx + 1) % (3 * NTI / 4) == 0) issue_part((idx + 1) / (3 * NTI / 4) - 1, t_issue, issue_stage);   // wave-uniform
         }
       } else {
-        // stem: a chunk is one tap, [h0 x 4][h1 x 4] (3 channels + a zero).  With the weight chunk as (w0, 0) the MFMA
-        // sums w0.x0, with its halves swapped, (w1, w0), it sums w1.x0 + w0.x1: two MFMAs per tile and half
+        // stem: a chunk is one tap, pixel [X0 x 4][X1 x 4] (3 channels + a zero), weight [P x 4][Q x 4].  With the weight
+        // chunk as (P, P 2^-11) the MFMA sums P.X0 + (P 2^-11).X1, as (Q, 0) it sums Q.X0: two MFMAs per tile and half
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          uint4 px[MT16], wz[NT16], ws[NT16];
+          uint4 px[MT16], wa[NT16], wb[NT16];
 #pragma unroll
           for (int i = 0; i < MT16; ++i) px[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, 4 * half + q16));
 #pragma unroll
           for (int j = 0; j < NT16; ++j) {
             const uint4 wv = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, 4 * half + q16));
-            wz[j] = make_uint4(wv.x, wv.y, 0u, 0u);
-            ws[j] = make_uint4(wv.z, wv.w, wv.x, wv.y);
+            const uint4 lo = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, wv) * kLow);
+            wa[j] = make_uint4(wv.x, wv.y, lo.x, lo.y);
+            wb[j] = make_uint4(wv.z, wv.w, 0u, 0u);
           }
 #pragma unroll
           for (int idx = 0; idx < 2 * NTI; ++idx) {
             const int prod = idx / NTI, n = idx % NTI, j = n / MT16, i = n % MT16;
-            if (prod == 0)
-              accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wz[j]), __builtin_bit_cast(f16x8, px[i]), accI2[j][i], 0, 0, 0);
-            else
-              accS2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ws[j]), __builtin_bit_cast(f16x8, px[i]), accS2[j][i], 0, 0, 0);
+            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, prod == 0 ? wa[j] : wb[j]), __builtin_bit_cast(f16x8, px[i]), accI2[j][i], 0, 0, 0);
             if (do_issue && (idx + 1) % NTI == 0) issue_part(2 * half + (idx + 1) / NTI - 1, t_issue, issue_stage);
           }
         }
@@ -719,14 +726,9 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? 3 : 
 #pragma unroll
     for (int n = 0; n < NTILES; ++n) acc[n / MT][n % MT] += accI[n / MT][n % MT];
   }
-  if constexpr (X2) {                                 // likewise, then the cross terms (they carry 2^11)
+  if constexpr (X2) {                                 // likewise
 #pragma unroll
-    for (int n = 0; n < NT16 * MT16; ++n) {
-      const int j = n / MT16, i = n % MT16;
-      const f32x4 big = acc16[j][i] + accI2[j][i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc16[j][i][e] = __builtin_fmaf(accS2[j][i][e], kH1Unscale, big[e]);
-    }
+    for (int n = 0; n < NT16 * MT16; ++n) acc16[n / MT16][n % MT16] += accI2[n / MT16][n % MT16];
   }
 
   // ---- epilogue.
@@ -897,13 +899,13 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// The tile menu.  rows x cols = pixels x channels; "blocks/CU" is what the LDS ring allows.
+// The tile menu.  rows x cols = pixels x channels; "blocks/CU" is what the LDS ring (and the registers) allow.
 //   id  tile      waves (m x n)  wave tile  stages  LDS      blocks/CU
 //   0   128x64    2x2            64x32      3       72 KiB   2
 //   1   128x128   2x2            64x64      2       64 KiB   2
-//   2   256x128   4x2            64x64      3       144 KiB  1
-//   3   256x256   2x4            128x64     2       128 KiB  1
-//   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch)
+//   2   256x128   4x2            64x64      3       144 KiB  1   (no f16x2 form: it spills)
+//   3   256x256   2x4            128x64     2       128 KiB  1   (bf16 only)
+//   4   128x128   2x2            64x64      4       128 KiB  1   (deeper prefetch; f32 / bf16)
 //   5   128x256   2x4            64x64      3       144 KiB  1
 //   6   256x64    4x2            64x32      3       120 KiB  1
 //   7   128x64    2x2            64x32      2       48 KiB   3   (short-K layers: K fits two stages)
@@ -911,20 +913,29 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 //   9   128x128   4x2            32x64      2       70 KiB   2   (8 waves: short-K layers, where the
 //   10  128x64    4x2            32x32      2       48 KiB   3    serial prologue/epilogue code dominates
 //   11  256x128   4x4            64x32      2       96 KiB   1    and more waves run it in parallel)
-//   13  128x128   2x4            64x32      3       96 KiB   1   (8 waves; the widest tile of the f16x2 mode, whose three
-//                                                               accumulator sets allow wave tiles of 64x32 at most)
-//   14  128x128   2x4 + 4        64x32      3       96 KiB   1   (f16x2 only: tile 13 with four loader waves, VAR 8; 8-11 %
-//                                                               faster on the 3x3 and long-K 1x1 layers)
-//   15  128x64    4x2 + 4        32x32      3       72 KiB   1   (f16x2 only: tile 10 with four loader waves; layer2's 3x3 at
-//                                                               batch 1, one block per CU anyway: 27 -> 24 us)
 //   12  256x256   4x4            64x64      2       128 KiB  1   (bf16: short-K layers at batch >= 2; the matrix pipe is
 //                                                               busier than with 8 waves, the clock lower: same TFLOP/s on
 //                                                               long-K layers, 2-5 % faster epilogue-heavy 1x1 layers)
+//   13  128x128   2x4            64x32      3       96 KiB   1   (8 waves)
+//   f16x2 only (9, 10 there with three stages):
+//   14  128x128   2x4 + 4        64x32      3       96 KiB   1   (13 with four loader waves, VAR 8: the tile of a layer whose
+//                                                               128x128 tiles number 256 or fewer, one per CU: layer3 at batch 1)
+//   15  128x64    4x2 + 4        32x32      3       72 KiB   1   (10 with four loader waves; layer2's 3x3 at batch 1)
+//   16  128x128   2x2 + 4        64x64      3       96 KiB   1   (four MFMA waves of 64x64 + four loader waves: ties 14)
+//   17  128x128   2x4            64x32      2       64 KiB   2   (13 with two stages at 128 registers: TWO blocks per CU, one's
+//                                                               barrier waits, prologue and epilogue under the other's MFMAs;
+//                                                               the tile of every layer with two or more 128x128 tiles per
+//                                                               CU: 0.51 of the mode's peak on the head conv and layer4's
+//                                                               3x3 against 0.45 for tile 14)
 template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
-  if constexpr (PREC == 2) {             // f16x2: wave tiles of two 32x32 blocks at most (three accumulator sets)
+  if constexpr (PREC == 2) {             // f16x2 (two accumulator sets: 64x64 wave tiles at most)
     switch (tile) {
       case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);
+      case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);
+      case 5: return launch_cfg<PREC, 2, 4, 2, 2, 3, STEM, VAR>(a, s);
+      case 16: return launch_cfg<PREC, 2, 2, 2, 2, 3, STEM, STEM ? VAR : 8>(a, s);    // 128x128 of 64x64 wave tiles + four loader waves
+      case 17: return launch_cfg<PREC, 2, 4, 2, 1, 2, STEM, VAR>(a, s);               // 13 with two stages: two blocks per CU
       case 6: return launch_cfg<PREC, 4, 2, 2, 1, 3, STEM, VAR>(a, s);
       case 7: return launch_cfg<PREC, 2, 2, 2, 1, 2, STEM, VAR>(a, s);
       case 8: return launch_cfg<PREC, 1, 4, 2, 1, 2, STEM, VAR>(a, s);
@@ -959,8 +970,8 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   }
 }
 
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64};
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128};
 
 }  // namespace
 
@@ -971,45 +982,57 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 bool conv_tile_ok(int precision, int tile, int Co) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
   if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
-  if (precision == 2 && !(tile == 0 || tile == 6 || tile == 7 || tile == 8 || tile == 9 || tile == 10 || tile >= 13)) return false;
+  if (precision == 2 && (tile == 2 || tile == 3 || tile == 4 || tile == 11 || tile == 12)) return false;   // f16x2: no wave tiles of 128x64, no
+                                                                   // 16-wave blocks; the 256x128 tile of 64x64 wave tiles spills
   if (precision != 2 && tile >= 14) return false;                  // the loader-wave tile is f16x2's (in bf16 a 256x128 tile
                                                                    // with loader waves ties the one without: section 6.4)
   return Co % kTileCols[tile] == 0;
 }
 
 // Default tile of a layer (what runs unless nbc_autotune has measured): the cheapest under a small cost model.
-// A launch takes as long as the CU with the most blocks: ceil(blocks / 256) blocks one after the other, each
-//   tile FLOPs / (per-CU matrix rate x eff[t])  +  ovh[t]  +  tile bytes x cb[t] / (50 GB/s)
-// (K = Cin*kh*kw products per output; tile bytes = the (rows + cols) x K operand panels + twice the output tile).
-// What matters most is the first factor: a 640x1024 image has 10 240 pixels at stride 8, so the head conv on
-// 128x128 tiles is 320 blocks = two rounds of which the second is a quarter full, on 64x128 tiles 640 blocks =
-// three per CU, a third faster.  Constants fitted to per-layer timings of every tile on 28 (precision, batch,
-// height) cases (scripts/tile_model_probe.py, scripts/fit_tile_model.py, profiles/r02_tile_model_fit.log):
-// the choice is within 0.1-0.5 % (f32) / 0.4-4.4 % (bf16) of the per-layer best, which is where nbc_autotune lands
-// too; the rule it replaces (largest tile that still gives 256 blocks) was 2-38 % off at heights other than 1024.
+// A launch takes as long as the CU with the most blocks: b = ceil(blocks / 256) of them, run in groups of cap[t] -- the
+// blocks of that tile a CU holds at once (LDS and registers): they share its matrix pipes, and their prologues and
+// epilogues overlap -- that is g = b / cap full groups and a rest of r = b % cap blocks:
+//   (g * cap / eff[t] + r / eff_r) * tile FLOPs / per-CU matrix rate  +  b * tile bytes * cb[t] / (50 GB/s)  +  ceil(b / cap) * ovh[t]
+// (K = Cin*kh*kw products per output; tile bytes = the (rows + cols) x K operand panels + twice the output tile; eff_r
+// lies between eff1[t], one block alone on its CU, and eff[t], cap blocks together).  What matters most is the block
+// count: a 640x1024 image has 10 240 pixels at stride 8, so the head conv on 128x128 tiles is 320 blocks = two rounds of
+// which the second is a quarter full, on 64x128 tiles 640 blocks = three per CU, a third faster; and whether a tile's
+// blocks come in pairs: the f16x2 128x128 tile of eight waves at two blocks per CU runs the long-K layers at 0.51 of
+// the mode's peak when every CU has two (or four) of them and at 0.33 when it has one, where the one-block-per-CU tile
+// with loader waves reaches 0.39-0.45.  Constants fitted to per-layer timings of every tile (scripts/tile_model_probe.py,
+// scripts/fit_tile_model.py): f32 and bf16 on 28 (precision, batch, height) cases (profiles/r02_tile_model_fit.log:
+// within 0.1-0.5 % (f32) / 0.4-4.4 % (bf16) of the per-layer best, which is where nbc_autotune lands too); f16x2 on
+// eight cases (profiles/r04_tile_model_fit_f16x2.log: 0.2-0.5 % from the per-layer best, unchanged when every constant is
+// perturbed by +-2 %: no choice sits on a knife edge).
 namespace {
 struct TileModel {
   double cu_flops_per_us;              // per-CU matrix rate the efficiencies refer to
-  double eff[CONV_TILE_COUNT], ovh_us[CONV_TILE_COUNT], cb[CONV_TILE_COUNT];
+  double eff[CONV_TILE_COUNT], eff1[CONV_TILE_COUNT], ovh_us[CONV_TILE_COUNT], cb[CONV_TILE_COUNT];
+  int cap[CONV_TILE_COUNT];
 };
 constexpr TileModel kTileModel[3] = {
     // f32: 157.3 TF / 256 CUs
     {157.3e6 / 256.0,
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80},
-     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
     // bf16: against the 1 400 TF/s the chip sustains on this kernel (power-limited), / 256 CUs
     {1400.0e6 / 256.0,
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80},
-     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0},
-     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0}},
-    // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs; fitted to
-    // eight (batch, height) cases (profiles/r03_tile_model_data_f16x2_*.json, r03_tile_model_fit_f16x2.log): 2.1-2.7 % from
-    // the per-layer best
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
+    // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs
     {839.0e6 / 256.0,
-     {0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.516, 0.5, 0.529, 0.5, 0.5, 0.5, 0.54, 0.5},
-     {3, 3, 3, 3, 3, 3, 3.422, 1.875, 1.495, 3, 1.746, 3, 3, 3, 3.293, 3},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}};
+     {0.418, 0.52, 0.5, 0.5, 0.5, 0.52, 0.42, 0.5, 0.485, 0.42, 0.469, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.541},
+     {0.38, 0.36, 0.5, 0.5, 0.5, 0.52, 0.42, 0.267, 0.36, 0.42, 0.38, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.36},
+     {3.008, 3.0, 3.0, 3.0, 3.0, 3.0, 3.003, 3.168, 2.76, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 2.996},
+     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.259, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.231},
+     {2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2}}};
 }  // namespace
 
 int choose_conv_tile(int M, int Co, int K, int precision) {
@@ -1022,10 +1045,14 @@ int choose_conv_tile(int M, int Co, int K, int precision) {
     if (!conv_tile_ok(precision, t, Co)) continue;
     const double rows = kTileRows[t], cols = kTileCols[t];
     const long long blocks = (long long)((M + kTileRows[t] - 1) / kTileRows[t]) * (Co / kTileCols[t]);
-    const double rounds = (double)((blocks + 255) / 256);
+    const long long b = (blocks + 255) / 256;
+    const int cap = tm.cap[t];
+    const long long g = b / cap, rest = b % cap;
+    const double eff_r = cap > 1 && rest > 0 ? tm.eff1[t] + (tm.eff[t] - tm.eff1[t]) * (double)(rest - 1) / (double)(cap - 1) : tm.eff[t];
     const double flops = rows * cols * 2.0 * K;
     const double bytes = (rows + cols) * K * eb + rows * cols * eb * 2.0;
-    const double cost = rounds * (flops / (tm.cu_flops_per_us * tm.eff[t]) + tm.ovh_us[t] + bytes * tm.cb[t] / 50.0e3);
+    const double cost = ((double)(g * cap) / tm.eff[t] + (double)rest / eff_r) * flops / tm.cu_flops_per_us +
+                        (double)b * bytes * tm.cb[t] / 50.0e3 + (double)((b + cap - 1) / cap) * tm.ovh_us[t];
     // ties (to 1e-9 relative) go to the larger tile: fewer L2 -> LDS bytes per FLOP
     if (best < 0 || cost < best_cost * (1.0 - 1e-9) ||
         (cost <= best_cost * (1.0 + 1e-9) && rows * cols > (double)kTileRows[best] * kTileCols[best])) {

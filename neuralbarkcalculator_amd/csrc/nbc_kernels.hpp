@@ -34,7 +34,7 @@ struct ConvArgs {
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16),
 // 2 = f16x2 (two f16 pieces per f32 value, three v_mfma_f32_16x16x32_f16 per product: split16.hpp)
 // LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
-constexpr int CONV_TILE_COUNT = 16;   // tile menu: see launch_tile() in conv_igemm_dma.hip
+constexpr int CONV_TILE_COUNT = 18;   // tile menu: see launch_tile() in conv_igemm_dma.hip
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 bool conv_tile_ok(int precision, int tile, int Co);   // the tile exists for the precision and divides Co

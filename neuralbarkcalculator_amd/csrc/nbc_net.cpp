@@ -188,9 +188,9 @@ void split_f16x2(float x, uint16_t* h0, uint16_t* h1) {
 // 128-byte K-step row segment; 4 = the stem's 16-byte tap) become [h0 x group][h1 x group].  33 M weights: the x86 F16C
 // conversion (round to nearest even, subnormals: IEEE, like split_f16x2) where the host has it, else the portable one.
 #if defined(__x86_64__)
-__attribute__((target("avx,f16c"))) static void split_groups_f16c(float* data, size_t nfloats, int group) {
+__attribute__((target("avx,f16c"))) static void split_groups_f16c(float* data, size_t nfloats, int group, float low_scale) {
   alignas(32) uint16_t h0[32], h1[32];
-  const __m256 scale = _mm256_set1_ps(2048.0f);
+  const __m256 scale = _mm256_set1_ps(low_scale);
   for (size_t g = 0; g + group <= nfloats; g += group) {
     float* x = data + g;
     if (group == 32) {
@@ -206,7 +206,7 @@ __attribute__((target("avx,f16c"))) static void split_groups_f16c(float* data, s
     } else {                                           // group 4
       const __m128 v = _mm_loadu_ps(x);
       const __m128i a = _mm_cvtps_ph(v, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
-      const __m128 r = _mm_mul_ps(_mm_sub_ps(v, _mm_cvtph_ps(a)), _mm_set1_ps(2048.0f));
+      const __m128 r = _mm_mul_ps(_mm_sub_ps(v, _mm_cvtph_ps(a)), _mm_set1_ps(low_scale));
       const __m128i b = _mm_cvtps_ph(r, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
       const uint64_t lo = (uint64_t)_mm_cvtsi128_si64(a), hi = (uint64_t)_mm_cvtsi128_si64(b);
       std::memcpy(x, &lo, 8);
@@ -216,22 +216,28 @@ __attribute__((target("avx,f16c"))) static void split_groups_f16c(float* data, s
 }
 #endif
 
-static void split_groups(float* data, size_t nfloats, int group) {
+// low_scale: what the low piece is multiplied by before it is rounded (2^11 for activations, 1 for the normalised weights)
+static void split_groups(float* data, size_t nfloats, int group, float low_scale) {
 #if defined(__x86_64__)
-  if (__builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx")) { split_groups_f16c(data, nfloats, group); return; }
+  if (__builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx")) { split_groups_f16c(data, nfloats, group, low_scale); return; }
 #endif
   uint16_t h0[32], h1[32];
   for (size_t g = 0; g + group <= nfloats; g += group) {
-    for (int i = 0; i < group; ++i) split_f16x2(data[g + i], &h0[i], &h1[i]);
+    for (int i = 0; i < group; ++i) {
+      h0[i] = f32_to_f16(data[g + i]);
+      h1[i] = f32_to_f16((data[g + i] - f16_to_f32(h0[i])) * low_scale);
+    }
     std::memcpy(data + g, h0, (size_t)group * 2);
     std::memcpy(reinterpret_cast<unsigned char*>(data + g) + group * 2, h1, (size_t)group * 2);
   }
 }
 
-// The power of two k that nbc_pack_weights multiplies a weight row by in f16x2 mode: largest finite |w| * 2^k in [1, 2).
-// 0 for a row of zeros (or of nothing finite).  Clamped to +-66 so that the BatchNorm scale the inverse is folded into
-// stays a normal f32 for any gamma / sqrt(var + eps) between 2^-60 and 2^60; a row beyond the clamp (largest weight below
-// 2^-67 or above 2^67) is moved by 2^+-66 and keeps the rest of its exponent.
+// The power of two k that nbc_pack_weights multiplies a weight row by in f16x2 mode: largest finite |w| * 2^k in
+// [2^14, 2^15), the top of f16's range (65504), which leaves the most room below: the high piece P = f16(w 2^k) and the
+// low piece Q = f16(w 2^k - P) stay normal f16 numbers for weights down to 2^-15 of the row's largest, and so does
+// P * 2^-11, which the kernel forms for the third product.  0 for a row of zeros (or of nothing finite).  Clamped to
+// [-66, 80] so that the BatchNorm scale the inverse is folded into stays a normal f32 for any gamma / sqrt(var + eps)
+// between 2^-46 and 2^60; a row beyond the clamp keeps the rest of its exponent.
 int f16x2_row_exponent(const float* row, size_t n) {
   float m = 0.f;
   for (size_t i = 0; i < n; ++i) {
@@ -241,8 +247,8 @@ int f16x2_row_exponent(const float* row, size_t n) {
   if (m == 0.f) return 0;
   int e = 0;
   (void)std::frexp(m, &e);                            // m = f * 2^e, f in [0.5, 1)
-  const int k = 1 - e;                                // m * 2^k in [1, 2)
-  return k > 66 ? 66 : (k < -66 ? -66 : k);
+  const int k = 15 - e;                               // m * 2^k in [2^14, 2^15)
+  return k > 80 ? 80 : (k < -66 ? -66 : k);
 }
 
 thread_local std::string g_last_error;
@@ -365,13 +371,14 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
             else reinterpret_cast<uint16_t*>(row)[kidx] = f32_to_bf16(v);
           }
     }
-    // f16x2: a convolution in front of a BatchNorm is scale-free, so a checkpoint may hold weight rows of any magnitude,
-    // and f16 pieces cannot: below 2.4e-4 the low piece is an f16 subnormal (the split keeps fewer and fewer bits, with
-    // finite results and no flag), beyond 65504 the high piece is infinite.  Every output channel's row is therefore
-    // multiplied by the power of two that puts its largest |w| into [1, 2) before the split -- exact -- and the f32
-    // BatchNorm scale of that channel by the inverse power below -- exact as well: the epilogue's fma(acc, scale, shift)
-    // sees 2^k acc * 2^-k scale.  What stays is relative to the row: a weight below 2^-13 of its row's largest loses low
-    // bits, an absolute error of 2^-36 of that largest weight.
+    // f16x2 weights.  A convolution in front of a BatchNorm is scale-free, so a checkpoint may hold weight rows of any
+    // magnitude, and f16 pieces cannot (subnormal below 6e-5, infinite beyond 65504).  Every output channel's row is
+    // therefore multiplied by the power of two 2^k that puts its largest |w| into [2^14, 2^15) -- exact -- and split
+    // into P = f16(w 2^k) and Q = f16(w 2^k - P) (the difference is exact; Q is NOT scaled, unlike the low piece of
+    // an activation): w 2^k = P + Q to 2^-23.  The kernel sums P.X0 + Q.X0 + (P 2^-11).X1 in ONE f32 chain (X0, X1 =
+    // the activation's pieces, X1 carrying 2^11), and the channel's f32 BatchNorm scale takes the 2^-k below -- exact:
+    // the epilogue's fma(acc, scale, shift) sees 2^k acc * 2^-k scale.  What remains is relative to the row: a weight
+    // below 2^-15 of its row's largest loses low bits (an absolute error of 2^-39 of that largest weight).
     std::vector<int> row_exp(precision == NBC_PREC_F16X2 ? c.cout : 0, 0);
     if (precision == NBC_PREC_F16X2) {
       const size_t row_floats = row_bytes / 4;
@@ -381,8 +388,8 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
         if (row_exp[o] != 0)
           for (size_t e = 0; e < row_floats; ++e) row[e] = std::ldexp(row[e], row_exp[o]);
       }
-      // element e of a row in its f32-sized slot -> 32-element groups [h0 x 32][h1 x 32] (stem: taps of 4)
-      split_groups(reinterpret_cast<float*>(base + p.w_off), (size_t)c.cout * row_bytes / 4, p.stem ? 4 : 32);
+      // element e of a row in its f32-sized slot -> 32-element groups [P x 32][Q x 32] (stem: taps of 4)
+      split_groups(reinterpret_cast<float*>(base + p.w_off), (size_t)c.cout * row_bytes / 4, p.stem ? 4 : 32, 1.0f);
     }
     // eval-mode BatchNorm as ATen applies it: alpha = gamma * invstd, beta = bias - mean * alpha
     const float* g = static_cast<const float*>(given[c.bn + ".weight"]->data);
@@ -395,8 +402,8 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
       const float invstd = 1.0f / std::sqrt(var[o] + kBnEps);
       const float alpha = g[o] * invstd;
       const float t = mu[o] * alpha;
-      // f16x2: the row's power of two comes off again here (exact unless alpha * 2^-k leaves f32's normal range, which
-      // f16x2_row_exponent's clamp keeps 2^40 away from for any alpha between 2^-60 and 2^60)
+      // f16x2: the row's power of two comes off again here (exact unless alpha * 2^-k leaves f32's normal range:
+      // f16x2_row_exponent's clamp)
       scale[o] = row_exp.empty() ? alpha : std::ldexp(alpha, -row_exp[o]);
       shift[o] = b[o] - t;
     }

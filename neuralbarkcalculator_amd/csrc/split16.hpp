@@ -11,6 +11,7 @@ namespace nbc {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 constexpr float kH1Scale = 2048.0f, kH1Unscale = 1.0f / 2048.0f;
+constexpr _Float16 kH1UnscaleH = (_Float16)(1.0f / 2048.0f);      // 2^-11 is a normal f16
 
 __device__ __forceinline__ void split16(float x, _Float16& h0, _Float16& h1) {
   h0 = (_Float16)x;

@@ -70,9 +70,10 @@ class FCNResNet50:
     """MI355X-native ``fcn_resnet50`` (3 classes, output stride 8, bicubic upsample), eval mode.
 
     precision: ``"fp32"`` -- f32 MFMA, the parity mode; ``"f16x2"`` -- f32-grade on the f16 matrix pipe: every f32
-    value kept as two f16 pieces, three exact f16 products per product, f32 two-level sums (include/nbc.h,
-    NBC_PREC_F16X2; same tolerances as "fp32" in the tests); ``"bf16"`` -- bf16 MFMA with f32 accumulation and f32
-    BatchNorm epilogue, the throughput mode.
+    value kept as two f16 pieces (to 2^-23 relative for |x| >= 2^-12, an absolute 2^-36 below; weight rows normalised by
+    a power of two per output channel, so their magnitude does not matter), three exact f16 products per product, f32
+    two-level sums (include/nbc.h, NBC_PREC_F16X2; same tolerances as "fp32" in the tests); ``"bf16"`` -- bf16 MFMA with
+    f32 accumulation and f32 BatchNorm epilogue, the throughput mode.
     """
 
     def __init__(self, precision: str = "fp32"):
@@ -319,9 +320,10 @@ class FCNResNet50:
             _lib.check(self._lib.nbc_nonfinite_peek_async(self._require_ctx(), host_word.data_ptr(), stream), "nbc_nonfinite_peek_async")
 
     def set_conv_tile(self, tile: int = -1):
-        """Tuning/test knob: tile -1 = per-layer choice,
-        0..12 = 128x64 / 128x128 / 256x128 / 256x256 / 128x128 (4 stages) / 128x256 / 256x64 /
-        128x64 (2 stages) / 64x128 / 128x128 (8 waves) / 128x64 (8 waves) / 256x128 (16 waves) / 256x256 (16 waves, bf16)."""
+        """Tuning/test knob: tile -1 = per-layer choice, 0..17 = one tile shape of the conv kernel (the menu:
+        include/nbc.h, nbc_set_conv_tile; e.g. 5 = 128x256, 14 = 128x128 with four loader waves and 17 = 128x128 at two
+        blocks per CU, both f16x2 only).  A tile that does not exist for the precision, or does not divide a layer's
+        Cout, is ignored for that layer: the planned tile runs."""
         _lib.check(self._lib.nbc_set_conv_tile(self._require_ctx(), int(tile)), "nbc_set_conv_tile")
 
     def autotune(self, x: torch.Tensor, reps: int = 3, objective: str = "latency"):

@@ -4,31 +4,44 @@ scripts/tile_model_probe.py and reports, per case, how far the model's choice, t
 nbc_autotune's pick are from the per-layer best.   python scripts/fit_tile_model.py a.json b.json [--fit]
 Without --fit it evaluates the constants below (the ones compiled into the library).
 
-  cost(t) = ceil(blocks(t) / 256) * ( tile FLOPs / (per-CU rate * eff[t]) + ovh[t] + tile bytes * cb[t] / 50 GB/s )
+  b = ceil(blocks(t) / 256) blocks on the fullest CU, run in groups of cap[t] (the blocks of the tile a CU holds at once:
+  they share its matrix pipes and their prologues / epilogues overlap), g = b // cap full groups and a rest of r = b % cap:
+  cost(t) = (g * cap / eff[t] + r / eff_r) * tile FLOPs / per-CU rate + b * tile bytes * cb[t] / 50 GB/s + ceil(b / cap) * ovh[t]
+  with eff_r between eff1[t] (one block alone on the CU) and eff[t] (cap blocks).  cap = 1 for every f32 and bf16 tile, where
+  this is the formula the constants were fitted with.
 
---fit: random coordinate search on the mean relative regret over the cases, pulled towards eff 0.85, ovh 4 us,
-cb 1 (f32: cb fixed at 0), then cross-validated between the two files."""
+--fit: random coordinate search on the mean relative regret over the cases, pulled towards the priors, evaluated under a
+fixed set of +-2 % perturbations of every constant (a choice that flips under such a perturbation is a knife edge: round 3's
+fit lost 16 % when its constants were rounded), then cross-validated between the two files."""
 import json
 import math
 import random
 import sys
 
-ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128]
-COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64]
+ROWS = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128]
+COLS = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128]
+CAP = {"fp32": [1] * 18, "bf16": [1] * 18,
+       "f16x2": [2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2]}      # blocks per CU (LDS and registers)
 NT = len(ROWS)
 # FLOPs per ms per CU the efficiencies refer to (f16x2: algorithmic FLOPs, three f16 MFMA FLOPs each: 2 517 / 3)
 PEAK = {"fp32": 157.3e12 / 256 * 1e-3, "bf16": 1400e12 / 256 * 1e-3, "f16x2": 839e12 / 256 * 1e-3}
 BYTE_MS = 1.0 / (50e9 * 1e-3)                                                # ms per byte at 50 GB/s
 MODEL = {
-    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80],
-                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * NT),
-    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80],
-                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0],
-                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
-    "f16x2": dict(eff=[0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.533, 0.516, 0.5, 0.529, 0.5, 0.5, 0.5, 0.54, 0.5],
-                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.422, 1.875, 1.495, 3.0, 1.746, 3.0, 3.0, 3.0, 3.293, 3.0], cb=[0.0] * NT),
+    "fp32": dict(eff=[0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80],
+                 ovh=[4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0], cb=[0.0] * NT),
+    "bf16": dict(eff=[0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80],
+                 ovh=[1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0, 4.0, 4.0],
+                 cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
+    # f16x2: fitted on eight cases (profiles/r04_tile_model_fit_f16x2.log), from priors read off the per-layer tables
+    # (achieved share of 839 TF on long-K layers, one block alone and cap blocks together)
+    "f16x2": dict(eff=[0.418, 0.52, 0.5, 0.5, 0.5, 0.52, 0.42, 0.5, 0.485, 0.42, 0.469, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.541],
+                  eff1=[0.38, 0.36, 0.5, 0.5, 0.5, 0.52, 0.42, 0.267, 0.36, 0.42, 0.38, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.36],
+                  ovh=[3.008, 3.0, 3.0, 3.0, 3.0, 3.0, 3.003, 3.168, 2.76, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 2.996],
+                  cb=[0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.259, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.231]),
 }
-F16X2_TILES = (0, 6, 7, 8, 9, 10, 13, 14, 15)
+for _m in MODEL.values():
+    _m.setdefault("eff1", list(_m["eff"]))
+F16X2_TILES = (0, 1, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 17)
 
 
 def tile_ok(prec, t, co):
@@ -73,7 +86,10 @@ def pick(r, prec, p):
         blocks = math.ceil(r["M"] / ROWS[t]) * (r["co"] // COLS[t])
         flops = ROWS[t] * COLS[t] * 2.0 * r["K"]
         nbytes = (ROWS[t] + COLS[t]) * r["K"] * eb + ROWS[t] * COLS[t] * eb * 2
-        cost = math.ceil(blocks / 256) * (flops / (PEAK[prec] * p["eff"][t]) + p["ovh"][t] * 1e-3 + nbytes * p["cb"][t] * BYTE_MS)
+        b, cap = math.ceil(blocks / 256), CAP[prec][t]
+        g, rest = b // cap, b % cap
+        eff_r = p["eff1"][t] + (p["eff"][t] - p["eff1"][t]) * (rest - 1) / (cap - 1) if cap > 1 and rest > 0 else p["eff"][t]
+        cost = (g * cap / p["eff"][t] + rest / eff_r) * flops / PEAK[prec] + b * nbytes * p["cb"][t] * BYTE_MS + math.ceil(b / cap) * p["ovh"][t] * 1e-3
         if best is None or cost < best_cost * (1 - 1e-9) or (cost <= best_cost * (1 + 1e-9) and ROWS[t] * COLS[t] > ROWS[best] * COLS[best]):
             best, best_cost = t, cost
     return best
@@ -96,27 +112,51 @@ def regret(data, prec, p, verbose=False):
     return s / max(n, 1)
 
 
+def jitters(n=6, amp=0.02, seed=7):
+    rnd = random.Random(seed)
+    return [{k: [1.0 + rnd.uniform(-amp, amp) for _ in range(NT)] for k in ("eff", "eff1", "ovh", "cb")} for _ in range(n)]
+
+
+def robust_regret(data, prec, p, js):
+    """Mean regret over the constants as they stand and under each fixed perturbation."""
+    tot = regret(data, prec, p)
+    for j in js:
+        q = {k: [v * f for v, f in zip(p[k], j[k])] for k in p}
+        tot += regret(data, prec, q)
+    return tot / (len(js) + 1)
+
+
 def fit(data, prec, iters=8000, seed=1, lam=0.002, start=None):
     random.seed(seed)
-    p = dict(eff=[0.5 if prec == "f16x2" else 0.85] * NT, ovh=[3.0 if prec == "f16x2" else 4.0] * NT, cb=[1.0 if prec == "bf16" else 0.0] * NT)
+    if prec == "f16x2":
+        p = dict(eff=[0.42, 0.52, 0.5, 0.5, 0.5, 0.52, 0.42, 0.42, 0.42, 0.42, 0.42, 0.5, 0.5, 0.44, 0.47, 0.40, 0.47, 0.54],
+                 eff1=[0.38, 0.36, 0.5, 0.5, 0.5, 0.52, 0.42, 0.36, 0.36, 0.42, 0.38, 0.5, 0.5, 0.44, 0.47, 0.40, 0.47, 0.36],
+                 ovh=[3.0] * NT, cb=[0.3] * NT)
+    else:
+        p = dict(eff=[0.85] * NT, eff1=[0.85] * NT, ovh=[4.0] * NT, cb=[1.0 if prec == "bf16" else 0.0] * NT)
     prior = {k: list(v) for k, v in p.items()}
     if start is not None:                 # --from-model: refine the compiled constants (e.g. after a tile joined the menu)
         p = {k: list(v) for k, v in start.items()}
+    js = jitters() if prec == "f16x2" else []
 
     def score(q):
-        pen = sum((a - b) ** 2 for a, b in zip(q["eff"], prior["eff"])) + 0.01 * sum((a - b) ** 2 for a, b in zip(q["ovh"], prior["ovh"])) \
-            + 0.1 * sum((a - b) ** 2 for a, b in zip(q["cb"], prior["cb"]))
-        return regret(data, prec, q) + lam * pen
+        pen = sum((a - b) ** 2 for a, b in zip(q["eff"], prior["eff"])) + sum((a - b) ** 2 for a, b in zip(q["eff1"], prior["eff1"])) \
+            + 0.01 * sum((a - b) ** 2 for a, b in zip(q["ovh"], prior["ovh"])) + 0.1 * sum((a - b) ** 2 for a, b in zip(q["cb"], prior["cb"]))
+        return robust_regret(data, prec, q, js) + lam * pen
     best = score(p)
     for _ in range(iters):
         q = {k: list(v) for k, v in p.items()}
         t, u = random.randrange(NT), random.random()
-        if u < 0.4:
-            q["eff"][t] = min(1.0, max(0.2, q["eff"][t] + random.gauss(0, 0.05)))
-        elif u < 0.7 or prec != "bf16":
-            q["ovh"][t] = min(12.0, max(0.0, q["ovh"][t] + random.gauss(0, 1.0)))
+        if u < 0.3:
+            q["eff"][t] = min(1.0, max(0.2, q["eff"][t] + random.gauss(0, 0.03)))
+            if CAP[prec][t] == 1:
+                q["eff1"][t] = q["eff"][t]
+        elif u < 0.45 and CAP[prec][t] > 1:
+            q["eff1"][t] = min(q["eff"][t], max(0.2, q["eff1"][t] + random.gauss(0, 0.03)))
+        elif u < 0.75 or prec == "fp32":
+            q["ovh"][t] = min(12.0, max(0.0, q["ovh"][t] + random.gauss(0, 0.7)))
         else:
-            q["cb"][t] = min(4.0, max(0.0, q["cb"][t] + random.gauss(0, 0.2)))
+            q["cb"][t] = min(4.0, max(0.0, q["cb"][t] + random.gauss(0, 0.15)))
         r = score(q)
         if r <= best:
             best, p = r, q
@@ -135,14 +175,16 @@ def main():
         if "--fit" in sys.argv:
             if len(sets) == 2:
                 for a, b, tag in ((sets[0], sets[1], "first -> second"), (sets[1], sets[0], "second -> first")):
-                    p = fit(a, prec, iters=4000)
+                    p = fit(a, prec, iters=2500)
                     print("%s cross-validation %s: mean regret %.2f %% on the fitted file, %.2f %% on the other"
                           % (prec, tag, regret(a, prec, p) * 100, regret(b, prec, p) * 100))
-            p = fit(everything, prec, iters=20000, start=MODEL[prec] if "--from-model" in sys.argv else None)
+            p = fit(everything, prec, iters=int(next((a.split("=")[1] for a in sys.argv if a.startswith("--iters=")), 6000)),
+                    start=MODEL[prec] if "--from-model" in sys.argv else None)
             print(prec, "fitted on all cases:", json.dumps({k: [round(v, 3) for v in vs] for k, vs in p.items()}))
         else:
             p = MODEL[prec]
-        print("%s: mean regret of the model's choice %.2f %%" % (prec, regret(everything, prec, p) * 100))
+        print("%s: mean regret of the model's choice %.2f %% (%.2f %% under +-2 %% perturbations of its constants)"
+              % (prec, regret(everything, prec, p) * 100, robust_regret(everything, prec, p, jitters()) * 100))
         regret(everything, prec, p, verbose=True)
 
 

@@ -14,7 +14,7 @@ import torch
 from neuralbarkcalculator_amd import synth
 from neuralbarkcalculator_amd.model import FCNResNet50
 
-N_TILES = 16
+N_TILES = 18
 out_path = sys.argv[1]
 cases = [(p, int(b), int(h)) for p, b, h in (c.split(":") for c in sys.argv[2].split())]
 dev = torch.device("cuda", 0)

@@ -171,14 +171,15 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
             want = torch.from_numpy(want).to(torch.bfloat16).float().numpy()   # RNE like the packer
         row_pow2 = np.ones(u.cout, np.float32)
         if prec == 2:
-            # every output channel's row is normalised by the power of two that puts its largest |w| into [1, 2)
-            # (exact), split, and the inverse goes into that channel's BatchNorm scale below
+            # every output channel's row is normalised by the power of two that puts its largest |w| into [2^14, 2^15)
+            # (exact) and split into P = f16(v), Q = f16(v - P) (Q not scaled, unlike an activation's low piece); the
+            # inverse power goes into that channel's BatchNorm scale below
             row_pow2 = _row_pow2(want)
             want = want * row_pow2[:, None]
-            assert (np.abs(want).max(1) >= 1).all() and (np.abs(want).max(1) < 2).all()
+            assert (np.abs(want).max(1) >= 2.0 ** 14).all() and (np.abs(want).max(1) < 2.0 ** 15).all()
             w0 = want.astype(np.float16).astype(np.float32)
             np.testing.assert_array_equal(g0, w0, err_msg=u.name)
-            np.testing.assert_array_equal(g1, ((want - w0) * np.float32(2048)).astype(np.float16).astype(np.float32), err_msg=u.name)
+            np.testing.assert_array_equal(g1, (want - w0).astype(np.float16).astype(np.float32), err_msg=u.name)
         else:
             np.testing.assert_array_equal(got, want, err_msg=u.name)
         off = align(off + u.cout * ksteps * 128)
@@ -195,19 +196,19 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
 
 
 def _row_pow2(rows):
-    """2^k per row with max |w| * 2^k in [1, 2) (1 for a row of zeros): what nbc_pack_weights normalises f16x2 rows by."""
+    """2^k per row with max |w| * 2^k in [2^14, 2^15) (1 for a row of zeros): what nbc_pack_weights normalises f16x2 rows by."""
     m = np.abs(rows).max(1).astype(np.float64)
-    k = np.where(m > 0, -np.floor(np.log2(np.where(m > 0, m, 1.0))), 0.0)
+    k = np.where(m > 0, 14 - np.floor(np.log2(np.where(m > 0, m, 1.0))), 0.0)
     return np.exp2(k).astype(np.float32)
 
 
 @pytest.mark.parametrize("log2_scale", [-20, -16, -12, 0, 10, 30])
 def test_f16x2_weight_rows_are_normalised_before_the_split(built_lib, sd_np, log2_scale):
-    """The f16 pieces of a weight hold it to 2^-23 only while both are normal f16 numbers (|w| >= 2.4e-4 as it stands).
-    nbc_pack_weights multiplies every output channel's row by a power of two first (largest |w| into [1, 2)) and the
+    """The f16 pieces of a weight hold it to 2^-23 only while both are normal f16 numbers.  nbc_pack_weights multiplies
+    every output channel's row by a power of two first (largest |w| into [2^14, 2^15), the top of f16's range) and the
     channel's f32 BatchNorm scale by the inverse, so a checkpoint whose convolution weights are 1e-6 (or 1e7) in
     magnitude -- a convolution in front of a BatchNorm is scale-free -- packs to the same pieces as the same network at
-    ordinary magnitudes, and pieces * 2^-k give every weight back to 2^-23 of the row's largest."""
+    ordinary magnitudes, and (P + Q) * 2^-k gives every weight back to 2^-23 of the row's largest."""
     name, bn = "backbone.layer3.2.conv2", "backbone.layer3.2.bn2"
     s = np.float32(2.0 ** log2_scale)
     sd = dict(sd_np)
@@ -231,7 +232,7 @@ def test_f16x2_weight_rows_are_normalised_before_the_split(built_lib, sd_np, log
             inv = np.float32(1.0) / np.sqrt(sd[bn + ".running_var"] + np.float32(1e-5), dtype=np.float32)
             k = 1.0 / _row_pow2(w).astype(np.float64)                                              # 2^-k per row
             np.testing.assert_array_equal(scale, (sd[bn + ".weight"] * inv) * k.astype(np.float32))
-            back = (g0.astype(np.float64) + g1.astype(np.float64) / 2048.0) * k[:, None]
+            back = (g0.astype(np.float64) + g1.astype(np.float64)) * k[:, None]
             err = np.abs(back - w).max(1) / np.abs(w).max(1)
             assert err.max() <= 2.0 ** -23, err.max()
         off = a(a(s_off + u.cout * 4) + u.cout * 4)
@@ -261,18 +262,18 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
 def test_default_conv_tile_cost_model(built_lib):
     """Host logic of the per-layer default tile (csrc/conv_igemm_dma.hip, choose_conv_tile): a valid tile for the
     precision and channel count, and the choices that matter most, where whole rounds of blocks on 256 CUs decide."""
-    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128]
-    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64]
+    rows = [128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128]
+    cols = [64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128]
     f = built_lib.nbc_default_conv_tile
     for prec in (0, 1, 2):
         for co in (64, 128, 256, 512, 1024, 2048):
             for m in (64, 1000, 8448, 9984, 16384, 65536, 131072, 524288):
                 for k in (64, 576, 2048, 18432):
                     t = f(m, co, k, prec)
-                    assert 0 <= t < 16 and co % cols[t] == 0
+                    assert 0 <= t < 18 and co % cols[t] == 0
                     assert not (prec == 0 and t in (3, 12))            # f32 has no 256x256 tile
-                    assert prec != 2 or t in (0, 6, 7, 8, 9, 10, 13, 14, 15)   # f16x2: wave tiles of 64x32 at most
-                    assert prec == 2 or t < 14                             # the loader-wave tiles are f16x2's
+                    assert prec != 2 or t not in (2, 3, 4, 11, 12)       # f16x2: wave tiles of 64x64 at most, no 16-wave blocks
+                    assert prec == 2 or t < 14                             # the loader-wave and two-blocks-per-CU tiles are f16x2's
     assert f(16384, 96, 64, 0) == -1 and f(16384, 512, 64, 7) == -1 and f(0, 512, 64, 0) == -1
     blocks = lambda t, m, co: -(-m // rows[t]) * (co // cols[t])
     # the head conv (3x3, 2048 -> 512) in f32 at 1024x1024: 16 384 pixels, one 256x128 / 128x256 tile per CU

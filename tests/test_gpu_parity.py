@@ -253,7 +253,7 @@ def test_errors_are_python_exceptions(gpu_fp32):
         FCNResNet50("fp32").to(DEV)(torch.zeros(1, 3, 16, 16, device=DEV))   # no weights
 
 
-@pytest.mark.parametrize("tile", list(range(16)))
+@pytest.mark.parametrize("tile", list(range(18)))
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_every_conv_kernel_variant(oracle_model, gpu_fp32, gpu_bf16, mode, tile):
     """Each conv kernel instantiation (every tile shape of the LDS-DMA kernel) against
@@ -288,12 +288,12 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
     try:
         model.set_conv_tile(-1)
         base = model(x)
-        for tile in range(16):
+        for tile in range(18):
             model.set_conv_tile(tile)
             assert torch.equal(model(x), base), f"tile {tile} changes the logits"
         model.set_conv_tile(-1)
         tiles = model.autotune(x, reps=2)
-        assert len(tiles) == 54 and all(0 <= t < 16 for t in tiles)
+        assert len(tiles) == 54 and all(0 <= t < 18 for t in tiles)
         assert torch.equal(model(x), base)
     finally:
         model.set_conv_tile(-1)
