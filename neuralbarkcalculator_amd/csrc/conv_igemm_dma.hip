@@ -149,6 +149,13 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_loader = SPEC && wave >= CW;        // wave-uniform
   const bool loads = !SPEC || is_loader, computes = !SPEC || !is_loader;
+  // f16x2 loader-wave tiles (eight MFMA waves, two per SIMD: wave w and wave w + CW/2): the second half runs its MFMAs
+  // one barrier behind the first (see the main loop).  Measured on every eight-wave tile (profiles/r04_f16x2_stagger.log):
+  // -3 ... -6 % on tile 14 and -9 ... -17 % on tile 15, nothing on tile 13, worse on the tiles whose waves also issue the
+  // refill DMAs at two blocks per CU (17: the two blocks already run out of phase, and the fragments that stay live
+  // across the barrier push it over 128 registers) -- so only where loader waves exist.
+  constexpr bool STAGGER = (PREC == 2) && !STEM && CW >= 8 && LW > 0;
+  const bool late_half = STAGGER && wave >= CW / 2 && wave < CW;
   NBC_STAMP(0);                                     // block start
 
   // ---- tile coordinates: blocks that share an XCD (blockIdx % 8) take a contiguous range of tiles, channel tiles
@@ -432,52 +439,82 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
     compute32(t > 0 && (t & (FLUSH - 1)) == 0, stage, more, all_issued, next_stage, do_issue, t_issue, issue_stage);
   };
 
-  // Fragments are double-buffered in registers: the ds_read_b128 of chunk pair ks+1 are issued
-  // before the MFMAs of chunk pair ks, so LDS latency hides under the matrix pipe.
-  auto compute = [&](int t, int stage, bool do_issue, int t_issue, int issue_stage) {
-    const unsigned char* sa = smem + stage * STAGE_BYTES;
-    const unsigned char* sb = sa + A_BYTES;
+  // f16x2 K-step in two parts, so that the two waves of a SIMD can run them out of phase (STAGGER below): the
+  // fragment reads of a ring slot into registers that live across the loop's barrier, and the MFMAs on them.
+  constexpr bool X2F = X2 && !STEM;
+  constexpr int XM = X2F ? MT16 : 1, XN = X2F ? NT16 : 1;
+  // staggered tiles: the late half's fragments live across the loop's barrier (elsewhere they are locals of a K-step)
+  constexpr bool X2_STAG = X2F && (WM * WN >= 8) && loader_waves(VAR) > 0;
+  uint4 sp0[X2_STAG ? XM : 1], sp1[X2_STAG ? XM : 1], sw0[X2_STAG ? XN : 1], sw1[X2_STAG ? XN : 1];
+  auto x2_flush = [&](int t) __attribute__((always_inline)) {
     if constexpr (X2) {
-      constexpr int NTI = NT16 * MT16;
       if (t > 0 && (t & 7) == 0) {                     // wave-uniform: the chain of the last eight K-steps joins the sum
 #pragma unroll
-        for (int n = 0; n < NTI; ++n) {
+        for (int n = 0; n < NT16 * MT16; ++n) {
           acc16[n / MT16][n % MT16] += accI2[n / MT16][n % MT16];
 #pragma unroll
           for (int e = 0; e < 4; ++e) accI2[n / MT16][n % MT16][e] = 0.f;
         }
       }
+    }
+  };
+  auto x2_read = [&](int stage, uint4 (&xp0)[XM], uint4 (&xp1)[XM], uint4 (&xw0)[XN], uint4 (&xw1)[XN]) __attribute__((always_inline)) {
+    if constexpr (X2F) {
+      // lane (r16, q16) reads, of row r16 of every 16-row block, chunk q16 (high pieces of channels 8*q16..) and chunk
+      // 4 + q16 (their low pieces)
+      const unsigned char* sa = smem + stage * STAGE_BYTES;
+      const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < MT16; ++i) {
+        xp0[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, q16));
+        xp1[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, 4 + q16));
+      }
+#pragma unroll
+      for (int j = 0; j < NT16; ++j) {
+        xw0[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, q16));
+        xw1[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, 4 + q16));
+      }
+    }
+  };
+  auto x2_mfma = [&](int t, bool do_issue, int t_issue, int issue_stage, uint4 (&xp0)[XM], uint4 (&xp1)[XM], uint4 (&xw0)[XN], uint4 (&xw1)[XN])
+      __attribute__((always_inline)) {
+    if constexpr (X2F) {
+      constexpr int NTI = NT16 * MT16;
       const f16x8 kLow = {kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH};
+      // product-major: two MFMAs on one accumulator are NTI instructions apart; the scaled high pieces of a weight
+      // block are formed right in front of the block's third products (four v_pk_mul_f16; hoisting them cost 0-3 %,
+      // profiles/r04_f16x2_kloop_schedule_variants_rejected.log)
+#pragma unroll
+      for (int idx = 0; idx < 3 * NTI; ++idx) {
+        const int prod = idx / NTI, n = idx % NTI, j = n / MT16, i = n % MT16;
+        if (prod == 0)
+          accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xw0[j]), __builtin_bit_cast(f16x8, xp0[i]), accI2[j][i], 0, 0, 0);
+        else if (prod == 1)
+          accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xw1[j]), __builtin_bit_cast(f16x8, xp0[i]), accI2[j][i], 0, 0, 0);
+        else {
+          if (i == 0) xw0[j] = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, xw0[j]) * kLow);      // P -> P 2^-11, in place
+          accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xw0[j]), __builtin_bit_cast(f16x8, xp1[i]), accI2[j][i], 0, 0, 0);
+        }
+        if (do_issue && (idx + 1) % (3 * NTI / 4) == 0) issue_part((idx + 1) / (3 * NTI / 4) - 1, t_issue, issue_stage);   // wave-uniform
+      }
+    }
+  };
+
+  // Fragments are double-buffered in registers: the ds_read_b128 of chunk pair ks+1 are issued
+  // before the MFMAs of chunk pair ks, so LDS latency hides under the matrix pipe.
+  auto compute = [&](int t, int stage, bool do_issue, int t_issue, int issue_stage) __attribute__((always_inline)) {
+    const unsigned char* sa = smem + stage * STAGE_BYTES;
+    const unsigned char* sb = sa + A_BYTES;
+    if constexpr (X2) {
+      constexpr int NTI = NT16 * MT16;
       if constexpr (!STEM) {
-        // lane (r16, q16) reads, of row r16 of every 16-row block, chunk q16 (high pieces of channels 8*q16..) and chunk
-        // 4 + q16 (their low pieces)
-        uint4 p0[MT16], p1[MT16], w0[NT16], w1[NT16];
-#pragma unroll
-        for (int i = 0; i < MT16; ++i) {
-          p0[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, q16));
-          p1[i] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * MT * 32 + i * 16 + r16, 4 + q16));
-        }
-#pragma unroll
-        for (int j = 0; j < NT16; ++j) {
-          w0[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, q16));
-          w1[j] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * NT * 32 + j * 16 + r16, 4 + q16));
-        }
-        // product-major: two MFMAs on one accumulator are NTI instructions apart; the scaled high pieces of a weight
-        // block are formed right in front of the block's third products (four v_pk_mul_f16)
-#pragma unroll
-        for (int idx = 0; idx < 3 * NTI; ++idx) {
-          const int prod = idx / NTI, n = idx % NTI, j = n / MT16, i = n % MT16;
-          if (prod == 0)
-            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p0[i]), accI2[j][i], 0, 0, 0);
-          else if (prod == 1)
-            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w1[j]), __builtin_bit_cast(f16x8, p0[i]), accI2[j][i], 0, 0, 0);
-          else {
-            if (i == 0) w0[j] = __builtin_bit_cast(uint4, __builtin_bit_cast(f16x8, w0[j]) * kLow);      // P -> P 2^-11, in place
-            accI2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w0[j]), __builtin_bit_cast(f16x8, p1[i]), accI2[j][i], 0, 0, 0);
-          }
-          if (do_issue && (idx + 1) % (3 * NTI / 4) == 0) issue_part((idx + 1) / (3 * NTI / 4) - 1, t_issue, issue_stage);   // wave-uniform
-        }
+        uint4 p0[XM], p1[XM], w0[XN], w1[XN];
+        x2_flush(t);
+        x2_read(stage, p0, p1, w0, w1);
+        x2_mfma(t, do_issue, t_issue, issue_stage, p0, p1, w0, w1);
       } else {
+        x2_flush(t);
+        const f16x8 kLow = {kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH};
         // stem: a chunk is one tap, pixel [X0 x 4][X1 x 4] (3 channels + a zero), weight [P x 4][Q x 4].  With the weight
         // chunk as (P, P 2^-11) the MFMA sums P.X0 + (P 2^-11).X1, as (Q, 0) it sums Q.X0: two MFMAs per tile and half
 #pragma unroll
@@ -665,8 +702,9 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
     prefetch_identity();                                         // no DMA is outstanding any more
     step32(T - 1, (T - 1) % S, false, false, 0, false, 0, 0);
   } else {
-  for (int t = 0; t < T - 1; ++t) {
-    // own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding
+  // top of K-step t: own DMAs of step t have landed when at most (S-2) younger steps' DMAs are outstanding; the
+  // barrier makes every wave's share visible and retires the reads of the slot about to be refilled
+  auto loop_top = [&](int t) __attribute__((always_inline)) {
 #ifdef NBC_STAMPS
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -680,6 +718,48 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
     if (t > 0) { st_vm += st1 - st0; st_bar += __builtin_amdgcn_s_memtime() - st1; }
 #endif
     if (t == 0) { NBC_STAMP(2); NBC_STAMP_CLK(11); }   // first K-step landed
+  };
+  if constexpr (STAGGER) {
+    // f16x2 blocks with two MFMA waves per SIMD.  In lock step both read their fragments behind the barrier -- eight
+    // waves x 12 KiB through one LDS: 384 cycles in which no MFMA issues -- and then share the matrix pipe, the older
+    // wave first: it waits at the next barrier for 0.3 of the loop, the pipe is busy for 0.57 of it (block timelines,
+    // profiles/r04_f16x2_block_timelines.log).  The second half of the block's MFMA waves therefore runs ONE BARRIER
+    // LATE: behind barrier t it issues the MFMAs of step t-1, whose fragments it read in front of the barrier, and
+    // then reads the fragments of step t while the first half computes on them: the reads of one half hide under
+    // the MFMAs of the other (MI355X_MICROARCH.md, two waves per SIMD, item 9).  Same products in the same order per
+    // wave: bit-identical results.  The late half's reads of slot t must have RETURNED before it arrives at barrier
+    // t+1 (the slot is refilled behind it): s_waitcnt lgkmcnt(0) in front of the barrier, which hipcc does not emit
+    // for a raw s_barrier.  Three loops, one per role, each with T-1 barriers (a loop per role keeps the early half's
+    // fragments out of the loop-carried state).
+    if (is_loader) {
+      for (int t = 0; t < T - 1; ++t) {
+        loop_top(t);
+        if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S);
+      }
+    } else if (!late_half) {
+      for (int t = 0; t < T - 1; ++t) {
+        loop_top(t);
+        x2_flush(t);
+        x2_read(t % S, sp0, sp1, sw0, sw1);
+        x2_mfma(t, false, 0, 0, sp0, sp1, sw0, sw1);
+      }
+    } else {
+      if (T > 1) {                                   // step 0: nothing to compute on yet
+        loop_top(0);
+        x2_read(0, sp0, sp1, sw0, sw1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      for (int t = 1; t < T - 1; ++t) {
+        loop_top(t);
+        x2_flush(t - 1);
+        x2_mfma(t - 1, false, 0, 0, sp0, sp1, sw0, sw1);
+        x2_read(t % S, sp0, sp1, sw0, sw1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  } else {
+  for (int t = 0; t < T - 1; ++t) {
+    loop_top(t);
     // the ring slot of step t-1 is free from here on.  With three or more stages its refill (step
     // t+S-1) is issued in four parts, one behind each MFMA cluster of this step; with two stages the
     // refill is needed at the very next barrier, so it is issued at once to give it the whole step.
@@ -694,6 +774,7 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
       compute(t, t % S, t + S - 1 < T, t + S - 1, (t + S - 1) % S);
     }
   }
+  }
   // last K-step, peeled: every DMA has retired, so the identity (residual) tile of the epilogue is
   // requested here and its HBM/MALL latency hides under the last MFMAs and the transposes below.
   wait_vmcnt<0>();
@@ -705,7 +786,14 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
 #endif
   if (computes) prefetch_identity();                 // (loader waves own no output rows: their row / channel indices lie outside the tile)
   if constexpr (F32) step32(T - 1, (T - 1) % S, false, false, 0, false, 0, 0);
-  else if (computes) compute(T - 1, (T - 1) % S, false, 0, 0);
+  else if constexpr (STAGGER) {
+    if (computes) {
+      if (late_half && T > 1) { x2_flush(T - 2); x2_mfma(T - 2, false, 0, 0, sp0, sp1, sw0, sw1); }       // the late half catches up
+      x2_flush(T - 1);
+      x2_read((T - 1) % S, sp0, sp1, sw0, sw1);
+      x2_mfma(T - 1, false, 0, 0, sp0, sp1, sw0, sw1);
+    }
+  } else if (computes) compute(T - 1, (T - 1) % S, false, 0, 0);
   }
   if constexpr (RES_PREFETCH2) {
     if (rtile && computes) {
