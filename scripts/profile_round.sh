@@ -14,12 +14,12 @@ out=$root/gpurun_out/profile_round
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 K=${K:-12}; W=${W:-3}
-python3 $root/bench.py --streams 1 --steps $K --warmup $W --bf16-steps $K --bf16-streams 1 --f32-steps $K --f32-streams 1 --no-cpu-baseline --no-parity --save-tiles $out/tiles.json > $out/bench_tiles.json 2> $out/bench_tiles.err
+python3 $root/bench.py --frames 8 --streams 1 --steps $K --warmup $W --bf16-steps $K --bf16-streams 1 --f32-steps $K --f32-streams 1 --no-cpu-baseline --no-parity --save-tiles $out/tiles.json > $out/bench_tiles.json 2> $out/bench_tiles.err
 cfgs=("f16x2 1 f16x2" "fp32 1 f32" "bf16 8 bf16")
 for cfg in "${cfgs[@]}"; do
   set -- $cfg; prec=$1; batch=$2; dt=$3
   d=$out/${dt}_b${batch}; mkdir -p $d
-  common="--precision $prec --batch $batch --streams 1 --steps $K --warmup $W --no-bf16-leg --no-f32-leg --no-cpu-baseline --no-parity --tiles-file $out/tiles.json"
+  common="--frames 8 --precision $prec --batch $batch --streams 1 --steps $K --warmup $W --no-bf16-leg --no-f32-leg --no-cpu-baseline --no-parity --tiles-file $out/tiles.json"
   rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 $root/bench.py $common --dump-ops $d/ops.json > $d/trace.log 2>&1
   echo "trace $cfg done"
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 $root/bench.py $common --no-op-events > $d/fetch.log 2>&1
