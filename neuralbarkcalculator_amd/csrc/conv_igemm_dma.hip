@@ -149,12 +149,13 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_loader = SPEC && wave >= CW;        // wave-uniform
   const bool loads = !SPEC || is_loader, computes = !SPEC || !is_loader;
-  // f16x2 loader-wave tiles (eight MFMA waves, two per SIMD: wave w and wave w + CW/2): the second half runs its MFMAs
-  // one barrier behind the first (see the main loop).  Measured on every eight-wave tile (profiles/r04_f16x2_stagger.log):
-  // -3 ... -6 % on tile 14 and -9 ... -17 % on tile 15, nothing on tile 13, worse on the tiles whose waves also issue the
-  // refill DMAs at two blocks per CU (17: the two blocks already run out of phase, and the fragments that stay live
-  // across the barrier push it over 128 registers) -- so only where loader waves exist.
-  constexpr bool STAGGER = (PREC == 2) && !STEM && CW >= 8 && LW > 0;
+  // f16x2 tiles of eight MFMA waves (two per SIMD: wave w and wave w + CW/2): the second half runs its MFMAs one barrier
+  // behind the first (see the main loop).  Measured on every eight-wave tile (profiles/r04_f16x2_stagger.log): -3 ... -6 %
+  // on tile 14 and -9 ... -17 % on tile 15 (loader waves), -2 ... -7 % on tile 5 (64x64 wave tiles), 0 ... -4 % on tiles
+  // 6, 9, 10, 13, and +2 ... +18 % on tile 17, whose two blocks per CU already run out of phase and whose 128 registers do
+  // not hold fragments that stay live across the barrier (19 spilled).  Kept where it pays: loader-wave tiles and
+  // 64x64 wave tiles.
+  constexpr bool STAGGER = (PREC == 2) && !STEM && CW >= 8 && (LW > 0 || MT * NT >= 4);
   const bool late_half = STAGGER && wave >= CW / 2 && wave < CW;
   NBC_STAMP(0);                                     // block start
 
@@ -444,7 +445,7 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   constexpr bool X2F = X2 && !STEM;
   constexpr int XM = X2F ? MT16 : 1, XN = X2F ? NT16 : 1;
   // staggered tiles: the late half's fragments live across the loop's barrier (elsewhere they are locals of a K-step)
-  constexpr bool X2_STAG = X2F && (WM * WN >= 8) && loader_waves(VAR) > 0;
+  constexpr bool X2_STAG = X2F && (WM * WN >= 8) && (loader_waves(VAR) > 0 || MT * NT >= 4);
   uint4 sp0[X2_STAG ? XM : 1], sp1[X2_STAG ? XM : 1], sw0[X2_STAG ? XN : 1], sw1[X2_STAG ? XN : 1];
   auto x2_flush = [&](int t) __attribute__((always_inline)) {
     if constexpr (X2) {
@@ -739,23 +740,33 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
     } else if (!late_half) {
       for (int t = 0; t < T - 1; ++t) {
         loop_top(t);
+        if constexpr (!SPEC && S == 2) { if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S); }
         x2_flush(t);
         x2_read(t % S, sp0, sp1, sw0, sw1);
-        x2_mfma(t, false, 0, 0, sp0, sp1, sw0, sw1);
+        x2_mfma(t, !SPEC && S > 2 && t + S - 1 < T, t + S - 1, (t + S - 1) % S, sp0, sp1, sw0, sw1);
       }
     } else {
+      // The older wave of a SIMD wins the arbitration for the matrix pipe; here that is the early half, which would push
+      // its MFMAs of step t in front of the late half's MFMAs of step t-1 and leave the late half's reads exposed at the end
+      // of the step.  With the late half at the higher priority its MFMAs run first (while the early half reads), then the
+      // early half's (while the late half reads): -3.6 ... -4.6 % on the long-K layers on tile 14, nothing on the 32x32
+      // wave tiles of tile 15 (profiles/r04_f16x2_stagger.log)
+      if constexpr (MT * NT >= 2) __builtin_amdgcn_s_setprio(1);
       if (T > 1) {                                   // step 0: nothing to compute on yet
         loop_top(0);
+        if constexpr (!SPEC) { if (S - 1 < T) issue_step(S - 1, (S - 1) % S); }
         x2_read(0, sp0, sp1, sw0, sw1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       for (int t = 1; t < T - 1; ++t) {
         loop_top(t);
+        if constexpr (!SPEC && S == 2) { if (t + S - 1 < T) issue_step(t + S - 1, (t + S - 1) % S); }
         x2_flush(t - 1);
-        x2_mfma(t - 1, false, 0, 0, sp0, sp1, sw0, sw1);
+        x2_mfma(t - 1, !SPEC && S > 2 && t + S - 1 < T, t + S - 1, (t + S - 1) % S, sp0, sp1, sw0, sw1);
         x2_read(t % S, sp0, sp1, sw0, sw1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+      if constexpr (MT * NT >= 2) __builtin_amdgcn_s_setprio(0);
     }
   } else {
   for (int t = 0; t < T - 1; ++t) {
@@ -1087,12 +1098,12 @@ bool conv_tile_ok(int precision, int tile, int Co) {
 // count: a 640x1024 image has 10 240 pixels at stride 8, so the head conv on 128x128 tiles is 320 blocks = two rounds of
 // which the second is a quarter full, on 64x128 tiles 640 blocks = three per CU, a third faster; and whether a tile's
 // blocks come in pairs: the f16x2 128x128 tile of eight waves at two blocks per CU runs the long-K layers at 0.51 of
-// the mode's peak when every CU has two (or four) of them and at 0.33 when it has one, where the one-block-per-CU tile
-// with loader waves reaches 0.39-0.45.  Constants fitted to per-layer timings of every tile (scripts/tile_model_probe.py,
+// the mode's peak when every CU has two (or four) of them and at 0.33 when it has one, where the one-block-per-CU tiles
+// (14 with loader waves, 5 with 64x64 wave tiles) reach 0.40-0.55.  Constants fitted to per-layer timings of every tile (scripts/tile_model_probe.py,
 // scripts/fit_tile_model.py): f32 and bf16 on 28 (precision, batch, height) cases (profiles/r02_tile_model_fit.log:
 // within 0.1-0.5 % (f32) / 0.4-4.4 % (bf16) of the per-layer best, which is where nbc_autotune lands too); f16x2 on
-// eight cases (profiles/r04_tile_model_fit_f16x2.log: 0.2-0.5 % from the per-layer best, unchanged when every constant is
-// perturbed by +-2 %: no choice sits on a knife edge).
+// eight cases (profiles/r04_tile_model_fit_f16x2.log: 0.2-1.6 % from the per-layer best, 0.9 % on average, and the same when
+// every constant is perturbed by +-2 %: no choice sits on a knife edge).
 namespace {
 struct TileModel {
   double cu_flops_per_us;              // per-CU matrix rate the efficiencies refer to
@@ -1116,10 +1127,10 @@ constexpr TileModel kTileModel[3] = {
      {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
     // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs
     {839.0e6 / 256.0,
-     {0.418, 0.52, 0.5, 0.5, 0.5, 0.52, 0.42, 0.5, 0.485, 0.42, 0.469, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.541},
-     {0.38, 0.36, 0.5, 0.5, 0.5, 0.52, 0.42, 0.267, 0.36, 0.42, 0.38, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.36},
-     {3.008, 3.0, 3.0, 3.0, 3.0, 3.0, 3.003, 3.168, 2.76, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 2.996},
-     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.259, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.231},
+     {0.421, 0.52, 0.5, 0.5, 0.5, 0.535, 0.42, 0.476, 0.42, 0.42, 0.455, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.501},
+     {0.38, 0.36, 0.5, 0.5, 0.5, 0.535, 0.42, 0.383, 0.36, 0.42, 0.392, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.36},
+     {3, 3, 3, 3, 3, 3.45, 3.007, 3, 2.746, 3, 2.868, 3, 3, 2.518, 3.874, 3, 3, 3.321},
+     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.309, 0.31, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.195},
      {2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2}}};
 }  // namespace
 

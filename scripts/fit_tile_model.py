@@ -34,10 +34,10 @@ MODEL = {
                  cb=[0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]),
     # f16x2: fitted on eight cases (profiles/r04_tile_model_fit_f16x2.log), from priors read off the per-layer tables
     # (achieved share of 839 TF on long-K layers, one block alone and cap blocks together)
-    "f16x2": dict(eff=[0.418, 0.52, 0.5, 0.5, 0.5, 0.52, 0.42, 0.5, 0.485, 0.42, 0.469, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.541],
-                  eff1=[0.38, 0.36, 0.5, 0.5, 0.5, 0.52, 0.42, 0.267, 0.36, 0.42, 0.38, 0.5, 0.5, 0.44, 0.47, 0.4, 0.449, 0.36],
-                  ovh=[3.008, 3.0, 3.0, 3.0, 3.0, 3.0, 3.003, 3.168, 2.76, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 2.996],
-                  cb=[0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.259, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.231]),
+    "f16x2": dict(eff=[0.421, 0.52, 0.5, 0.5, 0.5, 0.535, 0.42, 0.476, 0.42, 0.42, 0.455, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.501],
+                  eff1=[0.38, 0.36, 0.5, 0.5, 0.5, 0.535, 0.42, 0.383, 0.36, 0.42, 0.392, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.36],
+                  ovh=[3.0, 3.0, 3.0, 3.0, 3.0, 3.45, 3.007, 3.0, 2.746, 3.0, 2.868, 3.0, 3.0, 2.518, 3.874, 3.0, 3.0, 3.321],
+                  cb=[0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.309, 0.31, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.195]),
 }
 for _m in MODEL.values():
     _m.setdefault("eff1", list(_m["eff"]))
