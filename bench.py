@@ -83,7 +83,11 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the real multi-GPU path) or gloo (rehearsal)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (one-GPU box), implies a gloo process group")
-    ap.add_argument("--no-autotune", action="store_true", help="keep the default per-layer tile choice")
+    ap.add_argument("--autotune", choices=["auto", "on", "off"], default="auto",
+                    help="per-layer tiles by measurement in the set-up (nbc_autotune) or the library's default choice (its cost "
+                         "model): auto = default tiles for the f16x2 headline (318 images/s against 313 with measured tiles, two "
+                         "forwards in flight) and measured tiles for the f32 MFMA and bf16 legs, as in rounds 2 and 3")
+    ap.add_argument("--no-autotune", action="store_true", help="same as --autotune off")
     ap.add_argument("--tune-objective", choices=["auto", "latency", "throughput"], default="auto",
                     help="what nbc_autotune minimises: a launch's time alone, or time x share of the chip it occupies "
                          "(auto: throughput when several forwards are in flight)")
@@ -251,13 +255,17 @@ def main():
         installed = None
         if args.tiles_file:
             installed = json.load(open(args.tiles_file))
-        tune = not args.no_autotune and args.conv_tile < 0 and installed is None
+        want_tune = {"on": True, "off": False, "auto": precision != "f16x2"}["off" if args.no_autotune else args.autotune]
+        tune = want_tune and args.conv_tile < 0 and installed is None
         objective = ("throughput" if nstreams > 1 else "latency") if args.tune_objective == "auto" else args.tune_objective
         if tune:
             tiles = model.autotune(batches[0], reps=args.tune_reps, objective=objective)   # setup: per-layer tile shape by measurement
         elif installed is not None:
             tiles = installed[key]
             model.set_plan_tiles(tiles)
+        else:
+            tiles = model.plan_tiles()                # the library's default choice (or the forced tile where it fits)
+        leg["tiles_source"] = "nbc_autotune (%s objective)" % objective if tune else "installed from a file" if installed is not None else "library default (cost model)"
         models = [model]
         for _ in range(nstreams - 1):
             m2 = model.clone_shared()
@@ -303,7 +311,7 @@ def main():
         if instrument:
             if tune and nstreams > 1:
                 leg["tiles_one_stream"] = model.autotune(batches[0], objective="latency")
-            elif installed is not None and nstreams > 1:
+            elif installed is not None and nstreams > 1 and key + "_one_stream" in installed:
                 model.set_plan_tiles(installed[key + "_one_stream"])
             for i in range(min(warmup, 3)):
                 step(i, 0)
@@ -446,7 +454,7 @@ def main():
                                % (cfg, args.batch, DTYPE_NAME[args.precision] + (" (f32-grade)" if args.precision == "f16x2" else ""), args.weights),
                    "batch": args.batch, "frames": nf, "precision": args.precision, "shard": "images r, r+N, ... per rank",
                    "conv_tile": args.conv_tile, "streams": head["nstreams"],
-                   "autotuned_tiles": head["tiles"]},
+                   "tiles": head["tiles"], "tiles_source": head["tiles_source"]},
         "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
         "dist_backend": (args.dist_backend if dist is not None else None),
         "devices": "cuda:0 shared by every rank (rehearsal)" if args.share_gpu else "cuda:LOCAL_RANK, one GPU per rank",
@@ -528,7 +536,7 @@ def main():
         of = {
             "config": {"workload": "configs[1]: 1xMI355X per rank, batch=1, f32 activations/weights on v_mfma_f32_32x32x2_f32 (round 2's "
                                    "headline), synthetic 1024x1024x3 frames resident in HBM, forward + argmax + class counts",
-                       "batch": 1, "precision": "fp32", "streams": legf["nstreams"], "autotuned_tiles": legf["tiles"]},
+                       "batch": 1, "precision": "fp32", "streams": legf["nstreams"], "tiles": legf["tiles"], "tiles_source": legf["tiles_source"]},
             "value": world * legf["steps"] / legf["dt"], "unit": "images/s", "dtype": "f32", "dtype_note": DTYPE_NOTE["fp32"],
             "steps": legf["steps"], "warmup": legf["warmup"], "ms_per_step": 1e3 * legf["dt"] / legf["steps"],
             "setup": legf["setup"],
@@ -543,7 +551,7 @@ def main():
         o8 = {
             "config": {"workload": "configs[2]: 1xMI355X per rank, batch=8, bf16 activations/weights (f32 accumulate, fused f32 "
                                    "BN+ReLU epilogue), synthetic 1024x1024x3 frames resident in HBM, forward + argmax + class counts",
-                       "batch": 8, "precision": "bf16", "streams": leg8["nstreams"], "autotuned_tiles": leg8["tiles"]},
+                       "batch": 8, "precision": "bf16", "streams": leg8["nstreams"], "tiles": leg8["tiles"], "tiles_source": leg8["tiles_source"]},
             "value": world * 8 * leg8["steps"] / leg8["dt"], "unit": "images/s", "dtype": "bf16",
             "steps": leg8["steps"], "warmup": leg8["warmup"], "ms_per_step": 1e3 * leg8["dt"] / leg8["steps"],
             "setup": leg8["setup"],
