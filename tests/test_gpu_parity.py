@@ -599,7 +599,23 @@ def test_f16x2_out_of_range_activations_raise_the_flag(built_lib, sd_np):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(low32).all()) and not m32.nonfinite_seen()
     assert bool(torch.isnan(low16).any()) and not bool(torch.isinf(low16).any())
+    # the same word without a synchronisation: a 4-byte copy enqueued on the forward's stream (what the folder driver
+    # sends back with every batch)
+    word = torch.zeros(2, dtype=torch.int32).pin_memory()
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        m16.lowres_logits(x)
+        m16.nonfinite_peek_async(word[0:1])
+        m32.lowres_logits(x)
+        m32.nonfinite_peek_async(word[1:2])
+    side.synchronize()
+    assert int(word[0]) != 0 and int(word[1]) == 0
+    with pytest.raises(ValueError):
+        m16.nonfinite_peek_async(torch.zeros(1, dtype=torch.int32))                   # not pinned
     assert m16.nonfinite_seen(reset=False) and m16.nonfinite_seen() and not m16.nonfinite_seen()   # sticky until reset
     ok = FCNResNet50("f16x2").load_state_dict(sd_np).to(DEV)
     ok.predict_labels(x)
-    assert not ok.nonfinite_seen()
+    ok.nonfinite_peek_async(word[0:1])
+    torch.cuda.synchronize()
+    assert int(word[0]) == 0 and not ok.nonfinite_seen()
