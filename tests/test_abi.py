@@ -287,3 +287,14 @@ def test_default_conv_tile_cost_model(built_lib):
     assert rows[f(131072, 512, 18432, 1)] * cols[f(131072, 512, 18432, 1)] == 65536
     # the stem (Cout 64) only has 64-column tiles to choose from
     assert cols[f(262144, 64, 147, 0)] == 64 and cols[f(262144, 64, 147, 1)] == 64
+    # f16x2 (round 4: the model knows how many blocks of a tile a CU holds at once).  Long-K layers: the 128x256 tile of
+    # 64x64 wave tiles whose halves run out of phase (5), or two 128x128 blocks per CU (17); a layer with exactly one
+    # 128x128 tile per CU and only 256 output channels (layer3 at batch 1) cannot pair anything up and takes the
+    # loader-wave tile (14); the short-K 1x1 + identity layers with many blocks per CU take 17; a 640-row scan's head conv
+    # takes small tiles, three per CU, like in f32
+    assert f(16384, 512, 18432, 2) in (5, 17) and f(16384, 512, 4608, 2) in (5, 17)
+    assert f(16384, 256, 2304, 2) == 14 and f(16384, 256, 1024, 2) == 14
+    assert f(32768, 256, 2304, 2) in (5, 17)                       # the same layer at batch 2
+    assert f(16384, 2048, 512, 2) == 17 and f(16384, 1024, 256, 2) == 17 and f(65536, 256, 64, 2) == 17
+    t = f(10240, 512, 18432, 2)
+    assert rows[t] * cols[t] == 8192 and blocks(t, 10240, 512) == 640
