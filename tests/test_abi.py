@@ -298,3 +298,38 @@ def test_default_conv_tile_cost_model(built_lib):
     assert f(16384, 2048, 512, 2) == 17 and f(16384, 1024, 256, 2) == 17 and f(65536, 256, 64, 2) == 17
     t = f(10240, 512, 18432, 2)
     assert rows[t] * cols[t] == 8192 and blocks(t, 10240, 512) == 640
+
+
+def test_f16x2_row_normalisation_edge_rows(built_lib, sd_np):
+    """Rows the normalisation cannot scale: an all-zero output channel keeps its BatchNorm scale (and packs to zeros); a
+    row holding NaN or infinity is normalised by its largest FINITE weight and keeps the NaN / infinity in its pieces (the
+    logits then say so, like in the reference); a row of 1e-30 weights hits the clamp of the exponent and still packs to
+    finite pieces with a finite scale."""
+    name, bn = "backbone.layer2.1.conv1", "backbone.layer2.1.bn1"
+    w = sd_np[name + ".weight"].copy()
+    w[0] = 0.0
+    w[1, 0, 0, 0] = np.nan
+    w[2, 1, 0, 0] = np.inf
+    w[3] *= np.float32(1e-30)
+    sd = dict(sd_np)
+    sd[name + ".weight"] = w
+    blob, ref = pack_state_dict(sd, "f16x2"), pack_state_dict(sd_np, "f16x2")
+    off = 0
+    a = lambda v: (v + 255) // 256 * 256
+    for u in topology.conv_units():
+        ksteps = 7 if u.cin == 3 else u.k * u.k * u.cin * 4 // 128
+        wbytes = u.cout * ksteps * 128
+        s_off = a(off + wbytes)
+        if u.name == name:
+            row = ksteps * 128
+            scale = blob[s_off: s_off + u.cout * 4].view(np.float32)
+            pieces = blob[off: off + wbytes].view(np.float16).reshape(u.cout, -1).astype(np.float32)
+            inv = np.float32(1.0) / np.sqrt(sd[bn + ".running_var"] + np.float32(1e-5), dtype=np.float32)
+            assert (pieces[0] == 0).all() and scale[0] == sd[bn + ".weight"][0] * inv[0]          # k = 0: the plain BatchNorm scale
+            assert np.isnan(pieces[1]).any() and np.isfinite(scale[1]) and np.nanmax(np.abs(pieces[1])) < 2.0 ** 15
+            assert np.isinf(pieces[2]).any() and np.isfinite(scale[2])
+            assert np.isfinite(pieces[3]).all() and np.isfinite(scale[3]) and scale[3] != 0
+            np.testing.assert_array_equal(blob[off + 4 * row: off + wbytes], ref[off + 4 * row: off + wbytes])   # the other rows: untouched
+            return
+        off = a(a(s_off + u.cout * 4) + u.cout * 4)
+    raise AssertionError("unit not found")
