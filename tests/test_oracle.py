@@ -135,3 +135,26 @@ def test_numpy_restatement_agrees_with_torch_oracle(oracle_model, sd_np):
     clear = (top2[2] - top2[1]) > 1e-4 * scale            # away from float32-vs-float64 ties
     assert clear.mean() > 0.99
     assert np.array_equal(labels[clear], labels_t[0].numpy()[clear])
+
+
+def test_rescaled_conv_weights_leave_the_function_unchanged(sd_np):
+    """The premise of tests/test_gpu_configs.py::test_f32_grade_modes_with_rescaled_conv_weights: multiplying every
+    convolution's weights by a power of two, the following BatchNorm's running_mean by the same, its running_var by the
+    square, and its gamma by sqrt(var s^2 + eps) / (s sqrt(var + eps)) leaves the network's function unchanged (float64
+    evaluation: the only difference is the rounding of the float32 gamma)."""
+    from test_gpu_configs import rescale_conv_weights
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50
+    x = torch.from_numpy(np.stack([synth.make_input(5, 64, 96)])).double()
+    outs = []
+    for log2_scale in (0, -16, 10):
+        sd = sd_np if log2_scale == 0 else rescale_conv_weights(sd_np, 2.0 ** log2_scale)
+        m = OracleFCNResNet50()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        with torch.no_grad():
+            outs.append(m.double()(x))
+    rng = float(outs[0].abs().max())
+    for o in outs[1:]:
+        assert float((o - outs[0]).abs().max()) <= 5e-6 * rng
+    # and the weights really are where the test says: 2^-16 of a Kaiming initialisation is 1e-7 .. 1e-6
+    w = rescale_conv_weights(sd_np, 2.0 ** -16)["backbone.layer3.2.conv2.weight"]
+    assert 1e-8 < float(np.abs(w).mean()) < 2e-6
