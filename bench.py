@@ -16,8 +16,9 @@ synthetic 1024x1024x3 frames, in the f32-GRADE mode NBC_PREC_F16X2: every f32 va
 two f16 pieces (to 2^-23 relative for |x| >= 2^-12; weight rows normalised by a power of two per output channel), a
 product is three EXACT f16 products on v_mfma_f32_16x16x32_f16, sums are f32 in two levels.  It passes every test of the f32 mode under the SAME tolerances
 (tests/test_gpu_parity.py, tests/test_gpu_configs.py: logits within 5e-6 of the oracle's logit range, at most 4 label
-flips per megapixel, each adjudicated by float64) and sits CLOSER to a float64 evaluation than the f32 MFMA mode and
-than the CPU reference itself (profiles/r04_fp64_adjudication_*.json).  The f32 MFMA mode (v_mfma_f32_32x32x2_f32),
+flips per megapixel, each adjudicated by float64); its error against a float64 evaluation is at the f32 MFMA mode's level
+(4.2-5.2e-6 on logits of range 2-3.5, the f32 MFMA 4.0-6.2e-6, the CPU reference 3.6-4.5e-6:
+profiles/r04_fp64_adjudication_*).  The f32 MFMA mode (v_mfma_f32_32x32x2_f32),
 round 2's headline, rides along as ``f32_mfma_batch1``.
 Images are independent: N GPUs = N shards of the folder, no data-path collective,
 weak scaling; the collectives are the one-off RCCL broadcast of the packed weights (``setup``) and
@@ -59,7 +60,7 @@ DTYPE_NOTE = {
     "f16x2": "f32-grade: each f32 value as two f16 pieces (to 2^-23 relative for |x| >= 2^-12, an absolute 2^-36 below; weight rows "
              "normalised by a power of two per output channel, folded into the f32 BN scale), each product = 3 exact f16 products on "
              "v_mfma_f32_16x16x32_f16 (the dropped 4th is 2^-22 relative at worst), two-level f32 sums; same test tolerances as f32, "
-             "error against float64 below the f32 MFMA mode's (profiles/r04_fp64_adjudication_*.json)"}
+             "error against float64 at the f32 MFMA mode's level (profiles/r04_fp64_adjudication_*)"}
 
 
 def parse(argv=None):
