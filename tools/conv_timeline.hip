@@ -154,6 +154,20 @@ int main(int argc, char** argv) {
     const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 0x1, se = (hw >> 13) & 0x7;
     per_cu[((unsigned long long)xcc << 16) | (se << 8) | (sh << 4) | cu].push_back({h[b * 64], h[b * 64 + 6]});
   }
+  {  // which first-round blocks share a CU: histogram of the blockIdx distance of the first two blocks of every CU
+    std::map<unsigned long long, std::vector<int>> first;
+    for (int b = 0; b < nblk; ++b) {
+      if ((h[b * 64] - t0) * 0.01 >= 1.0) continue;
+      const unsigned long long id = h[b * 64 + 7];
+      const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 0xf;
+      first[((unsigned long long)xcc << 16) | (hw & 0xff00)].push_back(b);
+    }
+    std::map<int, int> hist;
+    for (auto& kv : first) if (kv.second.size() >= 2) ++hist[kv.second[1] - kv.second[0]];
+    std::printf("  first-round co-residents, blockIdx distance: ");
+    for (auto& kv : hist) std::printf(" %d x%d", kv.first, kv.second);
+    std::printf("\n");
+  }
   size_t maxb = 0, maxc = 0;
   for (auto& kv : per_cu) {
     maxb = std::max(maxb, kv.second.size());
