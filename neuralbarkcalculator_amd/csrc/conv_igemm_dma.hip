@@ -121,8 +121,9 @@ constexpr int min_waves_per_simd(int prec, int wm, int wn, int mt, int nt, int s
 // others only read fragments and issue MFMAs.  An LDS-DMA costs the wave that issues it 60-185 cycles
 // (MI355X_MICROARCH.md, cycle constants); an f16x2 K-step is 384 MFMA cycles per wave, so four to six DMAs per wave
 // and step in the MFMA waves' own instruction stream cost more than the arithmetic.
+typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));   // what __builtin_nontemporal_load accepts
 constexpr int loader_waves(int var) { return var == 8 ? 4 : 0; }
-template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR>
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR, bool BIGW>
 __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM * WN + loader_waves(VAR)) / 4 : min_waves_per_simd(PREC, WM, WN, MT, NT, S)) void conv_dma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int EB = PREC == 1 ? 2 : 4;           // f16x2: two f16 pieces per element, the f32 mode's geometry
@@ -169,8 +170,19 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
     const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   }
-  const int tile_n = bid % tiles_n;
-  const int tile_m = bid / tiles_n;
+  int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  // BIGW (f16x2 identity layers whose weights alone fill an XCD's 4 MiB L2 -- layer4's conv3: 2048 x 512 x 4 B; chosen by
+  // launch_tile): a 4 x 2 grid of XCDs over (pixel tiles, channel tiles) halves the weights an XCD walks, and the identity
+  // tile -- 64 KiB per block that nothing reads twice -- is loaded non-temporal, so that it does not push weight and input
+  // panels out.  Measured (profiles/r04_f16x2_big_weight_identity_layers.log): layer4 conv3 -5 ... -10 % with both, -3 % with
+  // either; every other identity layer LOSES 4-16 % with either (their panels fit beside the stream), hence the size test;
+  // and as a run-time branch around the loads it keeps them from being scheduled among the last MFMAs (half the gain),
+  // hence the template argument.  Which block computes which tile and how a load is hinted changes no result.
+  if (BIGW && (tiles_n & 1) == 0 && (tiles_m & 3) == 0) {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, rows = tiles_m >> 2, hc = tiles_n >> 1;
+    tile_m = (xcd >> 1) * rows + li / hc;
+    tile_n = (xcd & 1) * hc + li % hc;
+  }
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -815,8 +827,13 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
           int row = row0 + i * 32 + ps2 * PIX_PER_PASS;
           row = row < rows_valid ? row : rows_valid - 1;     // tail rows read a valid row; never stored
           const unsigned char* rp = rtile + ((unsigned)row * row_bytes + lane_chunk);
-          rpre2[i][ps2][0] = *reinterpret_cast<const uint4*>(rp);
-          rpre2[i][ps2][1] = *reinterpret_cast<const uint4*>(rp + 64);
+          if constexpr (BIGW) {
+            rpre2[i][ps2][0] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(rp)));
+            rpre2[i][ps2][1] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(rp + 64)));
+          } else {
+            rpre2[i][ps2][0] = *reinterpret_cast<const uint4*>(rp);
+            rpre2[i][ps2][1] = *reinterpret_cast<const uint4*>(rp + 64);
+          }
         }
     }
   }
@@ -978,12 +995,12 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
 #endif
 }
 
-template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 0>
+template <int PREC, int WM, int WN, int MT, int NT, int S, bool STEM, int VAR = 0, bool BIGW = false>
 hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int smem = ring_bytes(PREC, WM, WN, MT, NT, S) + 2048;     // ring (or scratch) + scale/shift table
   static std::atomic<unsigned long long> attr_done{0};     // bit d: attribute set on device d (one context per device)
-  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR>;
+  auto kern = &conv_dma_kernel<PREC, WM, WN, MT, NT, S, STEM, VAR, BIGW>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
   if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {   // setting it twice from two threads is harmless
@@ -1029,6 +1046,14 @@ hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 template <int PREC, bool STEM, int VAR>
 hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   if constexpr (PREC == 2) {             // f16x2 (two accumulator sets: 64x64 wave tiles at most)
+    // identity layers with 3 MiB of weights or more (layer4's conv3) on the 128-channel tiles they run on: see BIGW in the kernel
+    if constexpr (!STEM) {
+      if (a.res != nullptr && a.w_bytes >= (3u << 20)) {
+        if (tile == 17) return launch_cfg<PREC, 2, 4, 2, 1, 2, false, VAR, true>(a, s);
+        if (tile == 1) return launch_cfg<PREC, 2, 2, 2, 2, 2, false, VAR, true>(a, s);
+        if (tile == 14) return launch_cfg<PREC, 2, 4, 2, 1, 3, false, 8, true>(a, s);
+      }
+    }
     switch (tile) {
       case 0: return launch_cfg<PREC, 2, 2, 2, 1, 3, STEM, VAR>(a, s);
       case 1: return launch_cfg<PREC, 2, 2, 2, 2, 2, STEM, VAR>(a, s);

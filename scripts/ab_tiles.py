@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """A/B of library builds in ONE process on one box (cdna_hip_programming.md rule 24): per-layer durations of chosen conv
-tiles for two or more builds of libnbc_hip.so, rounds interleaved.
+tiles for two or more builds of libnbc_hip.so, rounds interleaved, every measurement on a model of its own that takes the
+addresses the previous one gave back (see --resident).
   gpurun -- 'python scripts/ab_tiles.py --libs neuralbarkcalculator_amd/libnbc_hip.so tools/_bin/libnbc_x.so --tiles 1,7,14,17'
 Each build gets its own model object (ctypes loads every path as its own library instance).  Timing only: an experimental
 build may compute garbage."""
@@ -26,6 +27,10 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--forwards", type=int, default=6)
 ap.add_argument("--layers", default="", help="comma-separated substrings; default: every conv")
 ap.add_argument("--out", default=None)
+ap.add_argument("--resident", action="store_true",
+                help="one model per build, alive side by side (the old behaviour).  Default: every measurement builds its model and "
+                     "destroys it again, builds taken in an order that rotates from round to round -- side by side each model has "
+                     "its own workspace addresses, and identical kernels then differ by up to 1 %% with their place in the list")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 sd = synth.make_state_dict("trained_like", seed=7)
@@ -47,7 +52,7 @@ def model_on(path):
     return m
 
 
-models = [model_on(p) for p in args.libs]
+models = [model_on(p) for p in args.libs] if args.resident else [None] * len(args.libs)
 tiles = [int(t) for t in args.tiles.split(",")]
 want = [s for s in args.layers.split(",") if s]
 
@@ -68,10 +73,15 @@ def records(m):
 out = {}
 for tile in tiles:
     per = [[] for _ in models]
-    for _ in range(args.rounds):
-        for k, m in enumerate(models):
+    for rnd in range(args.rounds):
+        for j in range(len(models)):
+            k = (j + rnd) % len(models)
+            m = models[k] if args.resident else model_on(args.libs[k])
             m.set_conv_tile(tile)
             per[k].append(records(m))
+            if not args.resident:
+                m._destroy()
+                del m
     names = [q["name"] for q in per[0][0]]
     med = [[float(np.median([rnd[i]["ms"] for rnd in per[k]])) * 1e3 for i in range(len(names))] for k in range(len(models))]
     out[tile] = dict(names=names, us=med)
