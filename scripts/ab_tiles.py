@@ -83,7 +83,8 @@ for tile in tiles:
                 m._destroy()
                 del m
     names = [q["name"] for q in per[0][0]]
-    med = [[float(np.median([rnd[i]["ms"] for rnd in per[k]])) * 1e3 for i in range(len(names))] for k in range(len(models))]
+    # by NAME: a build may launch its layers in another order
+    med = [[float(np.median([next(q["ms"] for q in rnd if q["name"] == n) for rnd in per[k]])) * 1e3 for n in names] for k in range(len(models))]
     out[tile] = dict(names=names, us=med)
     print("tile %d: conv launches per forward, us: " % tile + "  ".join("%s %.1f" % (os.path.basename(p), sum(med[k])) for k, p in enumerate(args.libs)))
     for i, n in enumerate(names):
