@@ -299,6 +299,25 @@ def test_tile_shape_and_autotune_do_not_change_results(gpu_fp32, gpu_bf16, mode)
         model.set_conv_tile(-1)
 
 
+def test_f16x2_big_weight_identity_layers_keep_the_logits(built_lib, sd_np):
+    """layer4's conv3 in f16x2 on tiles 17, 1 and 14 runs the BIGW form of the kernel (csrc/conv_igemm_dma.hip: a 4 x 2 grid
+    of XCDs over the tiles when the pixel tiles divide by four, non-temporal identity loads): at a size where the
+    grid applies (256 x 512 image: 2 048 output pixels = 16 pixel tiles of 128) and at one where it does not (17 tiles),
+    the logits equal those of a tile that has no such form, bit for bit."""
+    m = FCNResNet50("f16x2").load_state_dict(sd_np).to(DEV)
+    try:
+        for h, w in ((256, 512), (200, 328)):
+            x = frames([21], h, w).to(DEV)
+            m.set_conv_tile(7)
+            base = m(x)
+            assert torch.isfinite(base).all()
+            for tile in (17, 1, 14, -1):
+                m.set_conv_tile(tile)
+                assert torch.equal(m(x), base), f"tile {tile} at {h}x{w} changes the logits"
+    finally:
+        m.set_conv_tile(-1)
+
+
 @pytest.mark.perf
 @pytest.mark.parametrize("mode,batch,height,slack", [("fp32", 1, 640, 1.10), ("fp32", 2, 528, 1.10), ("bf16", 8, 720, 1.15)])
 def test_default_tiles_are_close_to_the_measured_choice(gpu_fp32, gpu_bf16, mode, batch, height, slack):
