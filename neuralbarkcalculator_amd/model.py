@@ -13,7 +13,7 @@ runs, ``torch.distributed`` (RCCL) for the one-off weight broadcast.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Mapping, Optional, Tuple
+from typing import Mapping, Optional, Tuple
 
 import numpy as np
 import torch

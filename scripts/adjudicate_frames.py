@@ -8,7 +8,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np
 import torch
 from neuralbarkcalculator_amd import synth
 from neuralbarkcalculator_amd.model import FCNResNet50
