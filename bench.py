@@ -103,6 +103,9 @@ def parse(argv=None):
     ap.add_argument("--bf16-steps", type=int, default=0, help="steps of the configs[2] leg (default: max(10, K/5))")
     ap.add_argument("--bf16-streams", type=int, default=2)
     ap.add_argument("--no-op-events", action="store_true", help="no instrumented region (no roofline object)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how often the headline's bracketed K-step region is run: `value` is the FIRST (the contract's region), "
+                         "`value_repeats` lists all of them, `value_median` their median (the line's own spread)")
     ap.add_argument("--save-tiles", default=None, help="write the measured per-layer tile choices (JSON) to this file")
     ap.add_argument("--tiles-file", default=None,
                     help="install the tile choices of an earlier run instead of measuring them (profiling runs: the trace "
@@ -223,7 +226,7 @@ def main():
         frames = list(pool.map(lambda i: synth.make_input(rank + world * i, H, W), range(nf)))
     frames_dev = None                                # the same frames in HBM, shared by the legs
 
-    def run_leg(precision, batch, nstreams, steps, warmup, instrument):
+    def run_leg(precision, batch, nstreams, steps, warmup, instrument, repeats=1):
         """One configuration: weights to every rank, workspace, per-layer tiles, W warm-up steps, the
         bracketed region of K steps, then (optionally) the instrumented region."""
         leg = {"setup": {}}
@@ -301,6 +304,8 @@ def main():
             step(i)
         torch.cuda.synchronize()
         dt = timed_region(steps)                      # (1) the contract's region: nothing but the hot path in it
+        # the same region again (each with its own barrier + synchronize bracket): the spread of the line itself
+        leg["dt_repeats"] = [dt] + [timed_region(steps) for _ in range(max(1, repeats) - 1)]
         leg.update(dt=dt, steps=steps, warmup=warmup, batch=batch, nstreams=nstreams, tiles=tiles,
                    model=model, precision=precision)
         # per-image rows (global_idx, H, W, count_1, count_2) of this rank's last step, as the folder driver gathers them
@@ -376,6 +381,12 @@ def main():
                 if "frac_of_peak" in t["dominant_kernel"]:
                     out["frac_rocprof_table"] = t["dominant_kernel"]["frac_of_peak"]
                     out["table"] = "profiles/%s" % os.path.basename(path)
+                    # the longest launch of the table (the head conv, classifier.0): in-kernel shader clock and matrix-pipe
+                    # utilisation of its PMC pass -- where the power limit shows (busy share x clock)
+                    hc = max((o for o in t.get("ops", []) if o.get("flops", 0) > 0), key=lambda o: o["median_us"], default=None)
+                    if hc is not None and "clock_ghz_in_pmc_pass" in hc:
+                        out["head_conv_rocprof_table"] = {"op": hc["op"], "median_us": hc["median_us"], "clock_ghz_in_pmc_pass": hc["clock_ghz_in_pmc_pass"],
+                                                          "mfma_util": hc.get("mfma_util"), "frac_of_peak": hc["tflops"] / peak}
                 out["traffic_note"] = ("rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch of the dominant kernel (separate PMC passes, "
                                        "L2-miss traffic incl. Infinity-Cache hits), from profiles/%s" % os.path.basename(path))
                 if "mfma_util" in t["dominant_kernel"]:     # matrix-pipe utilisation by hardware counters, same table
@@ -393,7 +404,7 @@ def main():
         return out
 
     # ---- headline: configs[1] in the reference's arithmetic
-    head = run_leg(args.precision, args.batch, max(1, args.streams), args.steps, args.warmup, not args.no_op_events)
+    head = run_leg(args.precision, args.batch, max(1, args.streams), args.steps, args.warmup, not args.no_op_events, args.repeats)
     # ---- configs[1] on the f32 MFMA (round 2's headline), when the headline is the f16x2 mode
     legf = None
     if not args.no_f32_leg and (args.precision, args.batch) == ("f16x2", 1):
@@ -444,6 +455,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * head["dt"] / args.steps,
+        # the bracketed K-step region run `--repeats` times back to back: `value` is the first, these are all of them
+        "value_repeats": [images / d for d in head["dt_repeats"]],
+        "value_median": images / sorted(head["dt_repeats"])[len(head["dt_repeats"]) // 2],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

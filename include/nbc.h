@@ -52,21 +52,42 @@ enum {
   NBC_PREC_F16X2 = 2  /* f32-grade on the 16-bit matrix pipe: every f32 value is kept as two f16 pieces, 4 bytes per element
                          like f32.
                          Activations: X0 = f16(x), X1 = f16((x - X0) * 2^11); x = X0 + X1 * 2^-11 to 2^-23 relative at
-                         worst (rms 4e-8: the f32 level) for |x| >= 2^-12 = 2.4e-4.  Below that X1 is an f16 subnormal
-                         and the error is ABSOLUTE, at most 2^-36 (1.5e-11): harmless in a sum next to values of ordinary
-                         size, and finite, so no flag reports it.  Beyond +-65504 (f16's range) a value turns into NaN,
-                         never into a silently wrong number (nbc_nonfinite_seen).
+                         worst (rms 4e-8: the f32 level) for |x| >= 2^-12 = 2.4e-4; below that X1 is an f16 subnormal
+                         and the error is ABSOLUTE, at most 2^-36 (1.5e-11); beyond +-65504 (f16's range) a value turns
+                         into NaN, never into a silently wrong number (nbc_nonfinite_seen).  A tensor between a
+                         BatchNorm and the next convolution is scale-free, so a checkpoint may hold activations of any
+                         magnitude: nbc_pack_weights therefore estimates every tensor's size from its producing
+                         BatchNorm (max over channels of |beta| + 3 |gamma| sqrt(var / (var + eps))) and stores a tensor whose estimate lies
+                         outside [2^-5, 2^7] times the power of two that brings it to [2, 4) -- folded into the
+                         producing launch's f32 (scale, shift) and, inverted, into the scale of every launch that reads
+                         it (one power per residual stream); exact, ReLU and max-pool being positively homogeneous, and
+                         0 for every tensor of an ordinary checkpoint.  The 2^-36 floor is then 2^-37 of the tensor's
+                         expected size or less, whatever that size was in the checkpoint; what remains is a tensor
+                         whose running statistics do not describe its data (an untrained BatchNorm behind weights
+                         of another scale), where the floor can reach the values again silently and overflow raises the
+                         flag.  nbc_read_activation returns the tensor as the network defines it (power taken off).
                          Weights: nbc_pack_weights multiplies every output channel's row by the power of two that puts
                          its largest |w| into [2^14, 2^15) -- exact -- splits it into P = f16(w 2^k), Q = f16(w 2^k - P)
                          (to 2^-23 of the row's largest weight; a weight below 2^-15 of it loses low bits, an absolute
                          error of 2^-39 of the largest) and folds 2^-k into the channel's f32 BatchNorm scale -- exact.
                          The magnitude of a checkpoint's weights therefore does not matter (a convolution in front of a
-                         BatchNorm is scale-free): 1e-6 or 1e6 pack to the same pieces.
+                         BatchNorm is scale-free): 1e-6 or 1e6 pack to the same pieces.  Limits, reported and not
+                         silent (nbc_packed_weights_flags / nbc_weights_flags): a row whose largest |w| lies below
+                         2^-51 or above 2^81 is normalised only as far as k in [-66, 80] reaches (NBC_PACK_ROW_CLAMPED),
+                         and a (scale, shift) that leaves f32's normal range under its powers of two is no longer exact
+                         (NBC_PACK_SCALE_RANGE); a caller that sees either runs NBC_PREC_FP32 (the folder driver does).
                          A product is P*X0 + Q*X0 + (P*2^-11)*X1, three EXACT f16 products on v_mfma_f32_16x16x32_f16,
                          summed in ONE f32 chain per 256 channels that joins a running f32 sum (two levels, like the f32
                          mode); the dropped Q*X1 is 2^-22 relative at worst.  Error against float64 at the level of
                          NBC_PREC_FP32 (profiles/r04_fp64_adjudication_*: 4.2-5.2e-6 on logits of range 2-3.5, the f32
                          MFMA 4.0-6.2e-6, the CPU reference 3.6-4.5e-6), same tolerances in the tests. */
+};
+
+/* What nbc_pack_weights had to give up (bits of nbc_packed_weights_flags / nbc_weights_flags; 0 = nothing): NBC_PREC_F16X2 only. */
+enum {
+  NBC_PACK_ROW_CLAMPED = 1,  /* a weight row beyond the reach of the row normalisation (largest |w| < 2^-51 or > 2^81): its
+                                pieces keep fewer bits than f32 */
+  NBC_PACK_SCALE_RANGE = 2   /* a BatchNorm scale / shift left f32's normal range under the powers of two folded into it */
 };
 
 /* Layout of the image handed to nbc_forward. */
@@ -136,6 +157,9 @@ size_t nbc_packed_weights_bytes(int precision);
  * (scale, shift) pair, reorders conv weights OIHW -> [O][kh][kw][I] (K-major panels, zero padded
  * to whole 128-byte K-steps), converts to the precision's element type, writes `blob`. */
 int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob, size_t blob_bytes);
+/* NBC_PACK_* bits of a packed blob in HOST memory (>= 0), or a negative error.  The bits ride in the blob's trailer, so
+ * a rank that received the blob by broadcast reads the same ones (nbc_weights_flags on its context). */
+int nbc_packed_weights_flags(const void* blob, size_t blob_bytes, int precision);
 
 /* ---- context --------------------------------------------------------------------------- */
 int nbc_create(nbc_ctx** out, int hip_device);
@@ -146,6 +170,13 @@ int nbc_destroy(nbc_ctx* ctx);
 int nbc_attach_weights(nbc_ctx* ctx, const void* dev_blob, size_t bytes, int precision);
 /* Convenience: pack on the host, allocate device memory owned by the context, upload. */
 int nbc_load_weights(nbc_ctx* ctx, const nbc_tensor* tensors, int n, int precision);
+/* NBC_PACK_* bits of the attached blob (read from its trailer when it was attached: a 1-KiB device-to-host copy), >= 0,
+ * or a negative error (no weights attached). */
+int nbc_weights_flags(nbc_ctx* ctx);
+/* The power of two a the output tensor of conv unit `name` (or "backbone.maxpool") is STORED with in the attached blob's
+ * precision: stored = 2^a x the tensor the network defines (0 outside NBC_PREC_F16X2 and for every tensor of an ordinary
+ * checkpoint; see NBC_PREC_F16X2).  Introspection / tests; NBC_ERR_INVALID for an unknown name. */
+int nbc_activation_exponent(nbc_ctx* ctx, const char* name, int32_t* exponent);
 /* Multi-GPU start-up (the reference has no counterpart: it is single-device,
  * predict.py:66-70): RCCL broadcast of the packed weight blob from rank `root` of `rccl_comm` (an
  * ncclComm_t of the host process, one rank per GPU) on `hip_stream`.  The root must have weights of
@@ -248,9 +279,10 @@ int nbc_set_plan_tiles(nbc_ctx* ctx, const int32_t* tiles, int n);
  * that mode cannot represent: a caller that runs unknown weights in f16x2 checks this after its last forward and falls
  * back to NBC_PREC_FP32 when it is raised (the folder driver does).  Synchronises the device. */
 int nbc_nonfinite_seen(nbc_ctx* ctx, int reset);
-/* The same word without a synchronisation: enqueues on hip_stream a copy of it to *host_dst (pinned host memory), valid
+/* The same word without a synchronisation: enqueues on hip_stream a copy of it to *host_dst, valid
  * once work enqueued behind it on that stream has been waited for; non-zero = raised by a forward that ran on this
- * context ahead of the copy.  The folder driver sends it along with every batch's labels, so that an f16x2 run of
+ * context ahead of the copy.  host_dst must be PINNED host memory (hipHostMalloc / hipHostRegister): a copy to pageable
+ * memory is staged and may block, which is what this call exists to avoid -- NBC_ERR_INVALID otherwise.  The folder driver sends it along with every batch's labels, so that an f16x2 run of
  * weights that mode cannot carry is abandoned at the first batch that shows it, not after the last. */
 int nbc_nonfinite_peek_async(nbc_ctx* ctx, uint32_t* host_dst, void* hip_stream);
 

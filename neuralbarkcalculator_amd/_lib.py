@@ -17,6 +17,7 @@ NBC_ERR_INVALID, NBC_ERR_KEYS, NBC_ERR_HIP, NBC_ERR_STATE, NBC_ERR_NOMEM = -1, -
 PREC_FP32, PREC_BF16, PREC_F16X2 = 0, 1, 2
 IN_F32_NCHW, IN_U8_NHWC = 0, 1
 LABEL_U8, LABEL_I64 = 0, 1
+PACK_ROW_CLAMPED, PACK_SCALE_RANGE = 1, 2      # NBC_PACK_* of include/nbc.h
 
 
 class NbcTensor(C.Structure):
@@ -50,6 +51,9 @@ SIGNATURES = {
     "nbc_packed_weights_bytes": (C.c_size_t, [C.c_int]),
     "nbc_split_f16x2": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "nbc_pack_weights": (C.c_int, [C.POINTER(NbcTensor), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "nbc_packed_weights_flags": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int]),
+    "nbc_weights_flags": (C.c_int, [C.c_void_p]),
+    "nbc_activation_exponent": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32)]),
     "nbc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "nbc_destroy": (C.c_int, [C.c_void_p]),
     "nbc_attach_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),

@@ -257,6 +257,12 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   auto issue_one = [&](int d, int t, unsigned sa) __attribute__((always_inline)) {
     if (d < A_PASSES) {
       const int i = d;
+#if defined(NBC_ABLATE) && (NBC_ABLATE == 5)
+      if (X2 && !STEM && ld_kw != 0) return;           // tool builds only: pixel rows fetched for one tap column in three (timing of a
+#endif                                                 // 3x3 K loop whose rows stay in LDS across the kernel's columns)
+#if defined(NBC_ABLATE) && (NBC_ABLATE == 6)
+      if (X2 && !STEM) return;                         // tool builds only: no pixel-row DMAs at all (weights only)
+#endif
       if constexpr (!STEM) {
         dma16_buf(a_off[i], xrsrc, sa + (unsigned)(ROWS_PER_PASS * 128 * i), (unsigned)ld_cb * 128u);
       } else {
@@ -278,6 +284,9 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   // each MFMA cluster (their SALU/VMEM issue then runs in the shadow of the matrix pipe).
   auto issue_part = [&](int part, int t, int stage) __attribute__((always_inline)) {
     if constexpr (VAR == 4 || VAR == 7) return;      // timing-only ablations: no refill DMAs in the loop
+#if defined(NBC_ABLATE) && (NBC_ABLATE == 2)
+    if constexpr (X2) return;                        // tool builds only (tools/build_variant.sh): f16x2 K loop without refill DMAs
+#endif
     const unsigned sa = smem_base + (unsigned)stage * STAGE_BYTES + wave_off;
 #pragma unroll
     for (int d = 0; d < L; ++d)
@@ -457,7 +466,7 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   constexpr bool X2F = X2 && !STEM;
   constexpr int XM = X2F ? MT16 : 1, XN = X2F ? NT16 : 1;
   // staggered tiles: the late half's fragments live across the loop's barrier (elsewhere they are locals of a K-step)
-  constexpr bool X2_STAG = X2F && (WM * WN >= 8) && (loader_waves(VAR) > 0 || MT * NT >= 4);
+  constexpr bool X2_STAG = STAGGER;                 // ONE predicate: which tiles stagger and whose fragments cross the barrier
   uint4 sp0[X2_STAG ? XM : 1], sp1[X2_STAG ? XM : 1], sw0[X2_STAG ? XN : 1], sw1[X2_STAG ? XN : 1];
   auto x2_flush = [&](int t) __attribute__((always_inline)) {
     if constexpr (X2) {
@@ -473,6 +482,14 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
   };
   auto x2_read = [&](int stage, uint4 (&xp0)[XM], uint4 (&xp1)[XM], uint4 (&xw0)[XN], uint4 (&xw1)[XN]) __attribute__((always_inline)) {
     if constexpr (X2F) {
+#if defined(NBC_ABLATE) && (NBC_ABLATE == 3 || NBC_ABLATE == 4)
+      // tool builds only: no fragment reads (the registers are marked written so that the MFMAs stay)
+#pragma unroll
+      for (int i = 0; i < XM; ++i) { asm volatile("" : "+v"(xp0[i].x), "+v"(xp0[i].y), "+v"(xp0[i].z), "+v"(xp0[i].w)); asm volatile("" : "+v"(xp1[i].x), "+v"(xp1[i].y), "+v"(xp1[i].z), "+v"(xp1[i].w)); }
+#pragma unroll
+      for (int j = 0; j < XN; ++j) { asm volatile("" : "+v"(xw0[j].x), "+v"(xw0[j].y), "+v"(xw0[j].z), "+v"(xw0[j].w)); asm volatile("" : "+v"(xw1[j].x), "+v"(xw1[j].y), "+v"(xw1[j].z), "+v"(xw1[j].w)); }
+      return;
+#endif
       // lane (r16, q16) reads, of row r16 of every 16-row block, chunk q16 (high pieces of channels 8*q16..) and chunk
       // 4 + q16 (their low pieces)
       const unsigned char* sa = smem + stage * STAGE_BYTES;
@@ -493,6 +510,18 @@ __global__ __launch_bounds__((WM * WN + loader_waves(VAR)) * 64, VAR == 8 ? (WM 
       __attribute__((always_inline)) {
     if constexpr (X2F) {
       constexpr int NTI = NT16 * MT16;
+#if defined(NBC_ABLATE) && (NBC_ABLATE == 1 || NBC_ABLATE == 4)
+      // tool builds only: fragments consumed, no MFMA
+#pragma unroll
+      for (int i = 0; i < XM; ++i) { asm volatile("" :: "v"(xp0[i].x), "v"(xp0[i].y), "v"(xp0[i].z), "v"(xp0[i].w)); asm volatile("" :: "v"(xp1[i].x), "v"(xp1[i].y), "v"(xp1[i].z), "v"(xp1[i].w)); }
+#pragma unroll
+      for (int j = 0; j < XN; ++j) { asm volatile("" :: "v"(xw0[j].x), "v"(xw0[j].y), "v"(xw0[j].z), "v"(xw0[j].w)); asm volatile("" :: "v"(xw1[j].x), "v"(xw1[j].y), "v"(xw1[j].z), "v"(xw1[j].w)); }
+      if (do_issue) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) issue_part(part, t_issue, issue_stage);
+      }
+      return;
+#endif
       const f16x8 kLow = {kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH};
       // product-major: two MFMAs on one accumulator are NTI instructions apart; the scaled high pieces of a weight
       // block are formed right in front of the block's third products (four v_pk_mul_f16; hoisting them cost 0-3 %,
@@ -1066,7 +1095,11 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
       case 9: return launch_cfg<PREC, 4, 2, 1, 2, 3, STEM, VAR>(a, s);
       case 10: return launch_cfg<PREC, 4, 2, 1, 1, 3, STEM, VAR>(a, s);
       case 13: return launch_cfg<PREC, 2, 4, 2, 1, 3, STEM, VAR>(a, s);
+#ifdef NBC_TILE14_S4
+      case 14: return launch_cfg<PREC, 2, 4, 2, 1, 4, STEM, STEM ? VAR : 8>(a, s);     // tool builds only: four ring slots
+#else
       case 14: return launch_cfg<PREC, 2, 4, 2, 1, 3, STEM, STEM ? VAR : 8>(a, s);     // 13 with four loader waves
+#endif
       case 15: return launch_cfg<PREC, 4, 2, 1, 1, 3, STEM, STEM ? VAR : 8>(a, s);     // 10 with four loader waves
       default: return hipErrorInvalidValue;
     }

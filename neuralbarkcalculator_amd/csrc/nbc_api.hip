@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -75,6 +76,8 @@ struct nbc_ctx {
   std::vector<nbc_op_record> records;
   std::map<std::string, int> act_of;        // conv unit name -> op index (keep mode)
   void* scratch256 = nullptr;               // 256 bytes of device scratch (min/max of the preprocessor resize)
+  int pack_flags = 0;                       // NBC_PACK_* of the attached blob (its trailer)
+  std::vector<int> act_exp;                 // per conv unit: power of two its output tensor is stored with (trailer)
   unsigned* nonfinite = nullptr;            // one device word: bit 0 = a forward produced a NaN / infinite logit (sticky)
   void* zones_ws = nullptr;                 // remove_small_zones workspace: bg bytes, parent ints, size ints
   size_t zones_px = 0;                      // pixels it is sized for
@@ -347,7 +350,16 @@ int nbc_attach_weights(nbc_ctx* c, const void* dev_blob, size_t bytes, int preci
   if (bytes < L.total_bytes) return set_error(NBC_ERR_INVALID, "nbc_attach_weights: blob smaller than the packed layout");
   if (reinterpret_cast<uintptr_t>(dev_blob) % 256 != 0)
     return set_error(NBC_ERR_INVALID, "nbc_attach_weights: blob must be 256-byte aligned");
+  // the trailer: pack flags and the powers of two the activation tensors are stored with (nbc_net.hpp)
+  int32_t meta[kMetaWords];
+  NBC_HIP(hipSetDevice(c->device));
+  NBC_HIP(hipMemcpy(meta, static_cast<const unsigned char*>(dev_blob) + L.meta_off, sizeof(meta), hipMemcpyDeviceToHost));
+  const int nunits = (int)conv_units().size();
+  if (meta[0] != kMetaMagic || meta[2] != nunits)
+    return set_error(NBC_ERR_INVALID, "nbc_attach_weights: not a blob of this library's nbc_pack_weights (trailer mismatch)");
   if (c->owned_weights && c->owned_weights != dev_blob) { (void)hipFree(c->owned_weights); c->owned_weights = nullptr; }
+  c->pack_flags = meta[1];
+  c->act_exp.assign(meta + kMetaExpBase, meta + kMetaExpBase + nunits);
   c->weights = static_cast<const unsigned char*>(dev_blob);
   c->layout = L;
   if (c->precision != precision) stash_plan(c);      // element size changed: another plan
@@ -428,6 +440,33 @@ int nbc_bcast_weights(nbc_ctx* c, void* rccl_comm, int root, int precision, void
   return NBC_OK;
 }
 
+int nbc_weights_flags(nbc_ctx* c) {
+  if (!c) return set_error(NBC_ERR_INVALID, "null context");
+  if (!c->weights) return set_error(NBC_ERR_STATE, "nbc_weights_flags: no weights attached");
+  return c->pack_flags;
+}
+
+namespace {
+// power of two the output of plan op `name` is stored with: a conv unit's own, the max-pool keeps the stem's, the image has none
+bool stored_exponent(const nbc_ctx* c, const std::string& name, int* e) {
+  const auto& units = conv_units();
+  if (name == "ingest") { *e = 0; return true; }
+  if (name == "backbone.maxpool") { *e = c->act_exp.empty() ? 0 : c->act_exp[0]; return true; }
+  for (size_t u = 0; u < units.size(); ++u)
+    if (units[u].name == name) { *e = u < c->act_exp.size() ? c->act_exp[u] : 0; return true; }
+  return false;
+}
+}  // namespace
+
+int nbc_activation_exponent(nbc_ctx* c, const char* name, int32_t* exponent) {
+  if (!c || !name || !exponent) return set_error(NBC_ERR_INVALID, "nbc_activation_exponent: null argument");
+  if (!c->weights) return set_error(NBC_ERR_STATE, "nbc_activation_exponent: no weights attached");
+  int e = 0;
+  if (!stored_exponent(c, name, &e)) return set_error(NBC_ERR_INVALID, std::string("nbc_activation_exponent: unknown op ") + name);
+  *exponent = e;
+  return NBC_OK;
+}
+
 int nbc_set_normalization(nbc_ctx* c, const float mean[3], const float stdv[3]) {
   if (!c || !mean || !stdv) return set_error(NBC_ERR_INVALID, "nbc_set_normalization: null argument");
   for (int i = 0; i < 3; ++i) { c->mean[i] = mean[i]; c->stdv[i] = stdv[i]; }
@@ -461,8 +500,17 @@ int nbc_nonfinite_seen(nbc_ctx* c, int reset) {
 
 int nbc_nonfinite_peek_async(nbc_ctx* c, uint32_t* host_dst, void* hip_stream) {
   if (!c || !host_dst) return set_error(NBC_ERR_INVALID, "nbc_nonfinite_peek_async: null argument");
-  if (!c->nonfinite) { *host_dst = 0; return NBC_OK; }   // no forward yet
   NBC_HIP(hipSetDevice(c->device));
+  {
+    // pinned memory only: a copy to pageable memory is staged and may block (the contract is "no synchronisation")
+    hipPointerAttribute_t at{};
+    const hipError_t pe = hipPointerGetAttributes(&at, host_dst);
+    if (pe != hipSuccess || at.type != hipMemoryTypeHost) {
+      (void)hipGetLastError();
+      return set_error(NBC_ERR_INVALID, "nbc_nonfinite_peek_async: host_dst must be pinned host memory (hipHostMalloc / hipHostRegister)");
+    }
+  }
+  if (!c->nonfinite) { *host_dst = 0; return NBC_OK; }   // no forward yet
   NBC_HIP(hipMemcpyAsync(host_dst, c->nonfinite, sizeof(uint32_t), hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
   return NBC_OK;
 }
@@ -783,6 +831,9 @@ int nbc_read_activation(nbc_ctx* c, const char* name, float* dst_host, size_t ca
   if (e == hipSuccess) e = hipMemcpy(dst_host, tmp, elems * sizeof(float), hipMemcpyDeviceToHost);
   (void)hipFree(tmp);
   if (e != hipSuccess) return set_error(NBC_ERR_HIP, std::string("nbc_read_activation: ") + hipGetErrorString(e));
+  int a = 0;
+  if (stored_exponent(c, o.name, &a) && a != 0)        // f16x2: the tensor as the network defines it (power of two taken off, exact)
+    for (size_t i = 0; i < elems; ++i) dst_host[i] = std::ldexp(dst_host[i], -a);
   if (shape) { shape[0] = N; shape[1] = o.Co; shape[2] = o.Ho; shape[3] = o.Wo; }
   return NBC_OK;
 }

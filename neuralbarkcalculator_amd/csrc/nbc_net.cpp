@@ -2,6 +2,7 @@
 // No HIP calls in this file (it is also what the CPU-only tests exercise).
 #include "nbc_net.hpp"
 
+#include <algorithm>
 #include <cmath>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -132,6 +133,8 @@ PackedLayout packed_layout(int precision) {
     }
     L.convs.push_back(p);
   }
+  L.meta_off = off;
+  off = align_up(off + (size_t)kMetaWords * 4, 256);
   L.total_bytes = off;
   return L;
 }
@@ -238,7 +241,8 @@ static void split_groups(float* data, size_t nfloats, int group, float low_scale
 // P * 2^-11, which the kernel forms for the third product.  0 for a row of zeros (or of nothing finite).  Clamped to
 // [-66, 80] so that the BatchNorm scale the inverse is folded into stays a normal f32 for any gamma / sqrt(var + eps)
 // between 2^-46 and 2^60; a row beyond the clamp keeps the rest of its exponent.
-int f16x2_row_exponent(const float* row, size_t n) {
+int f16x2_row_exponent(const float* row, size_t n, bool* clamped) {
+  if (clamped) *clamped = false;
   float m = 0.f;
   for (size_t i = 0; i < n; ++i) {
     const float a = std::fabs(row[i]);
@@ -248,7 +252,100 @@ int f16x2_row_exponent(const float* row, size_t n) {
   int e = 0;
   (void)std::frexp(m, &e);                            // m = f * 2^e, f in [0.5, 1)
   const int k = 15 - e;                               // m * 2^k in [2^14, 2^15)
+  if (clamped) *clamped = k > 80 || k < -66;
   return k > 80 ? 80 : (k < -66 ? -66 : k);
+}
+
+// f16x2: the power of two every activation tensor is STORED with.  An activation between a BatchNorm (+ ReLU, + max-pool:
+// positively homogeneous) and the next convolution is scale-free, so a checkpoint (models.py:222 takes any) may hold tensors
+// of any magnitude, and f16 pieces cannot: below 2^-12 the low piece of a value is an f16 subnormal (an ABSOLUTE error of
+// 2^-36, which is everything once a whole tensor sits down there), beyond 65 504 the high piece overflows.  The pieces of an
+// activation are formed on the fly, so the cure sits in the f32 epilogue that produces the tensor: its magnitude is
+// estimated from the producing BatchNorm, est = max over channels of |beta| + 3 |gamma| sqrt(var / (var + eps)) (what a channel
+// reaches at three standard deviations when the running statistics describe the data: they do for a trained checkpoint and for every
+// rescaling of one), a tensor whose estimate lies outside [2^-5, 2^7] gets the power of two 2^a that brings it to [2, 4),
+// and the launch that PRODUCES the tensor applies scale 2^a, shift 2^a (its f32 BatchNorm pair), every launch that READS it
+// scale 2^-a: fma(2^a_in acc, 2^(a_out - a_in) scale, 2^a_out shift) = 2^a_out fma(acc, scale, shift), exact.  A residual
+// stream is ONE tensor as far as this goes (bn3 of every block of a stage and the downsample BatchNorm of its first add into
+// it): one power per stage.  Tensors of ordinary size keep a = 0, so an ordinary checkpoint computes what it computed before
+// this existed, bit for bit.  classifier.4 reads the last tensor with f32 weights: they take the 2^-a.
+// out_exp[u] / in_exp[u]: power of conv unit u's output tensor / of the tensor it reads.
+static int tensor_exponent(float est) {
+#ifdef NBC_NO_ACT_EXP
+  return 0;                                           // tool builds only (scripts/act_floor_probe.py): the library before this existed
+#endif
+  if (!(est > 0.f) || !std::isfinite(est)) return 0;
+  if (est >= 0.03125f && est <= 128.0f) return 0;
+  int e = 0;
+  (void)std::frexp(est, &e);                          // est = f * 2^e, f in [0.5, 1)
+  const int a = 2 - e;                                // est * 2^a in [2, 4)
+  return a > 100 ? 100 : (a < -100 ? -100 : a);
+}
+
+// gamma counts with the share of the normalised value that is data: a channel whose running variance lies below eps comes
+// out of the BatchNorm with a standard deviation of gamma sqrt(var / (var + eps)), not gamma
+static float bn_estimate(const float* gamma, const float* beta, const float* var, int n) {
+  float m = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float vr = var[i] > 0.f ? var[i] : 0.f;
+    const float v = std::fabs(beta[i]) + 3.0f * std::fabs(gamma[i]) * std::sqrt(vr / (vr + kBnEps));
+    if (std::isfinite(v) && v > m) m = v;
+  }
+  return m;
+}
+
+static void activation_exponents(const std::vector<const float*>& gamma, const std::vector<const float*>& beta,
+                          const std::vector<const float*>& var, std::vector<int>& out_exp, std::vector<int>& in_exp) {
+  const auto& units = conv_units();
+  const size_t n = units.size();
+  out_exp.assign(n, 0);
+  in_exp.assign(n, 0);
+  auto est = [&](size_t u) { return bn_estimate(gamma[u], beta[u], var[u], units[u].cout); };
+  int cur = tensor_exponent(est(0));                  // the stem's output (the max-pool keeps it)
+  out_exp[0] = cur;
+  size_t ui = 1;
+  while (ui < n && units[ui].block_first) {
+    // the units of one stage: bottlenecks up to (not including) the next one that has a downsample branch
+    size_t end = ui;
+    std::vector<size_t> c1, c2, c3, ds;
+    bool first = true;
+    while (end < n && units[end].block_first) {
+      const bool has_ds = !units[end + 2].residual;
+      if (has_ds && !first) break;
+      c1.push_back(end); c2.push_back(end + 1);
+      if (has_ds) { ds.push_back(end + 2); c3.push_back(end + 3); end += 4; }
+      else { c3.push_back(end + 2); end += 3; }
+      first = false;
+    }
+    float stream = 0.f;
+    for (size_t u : c3) stream = std::max(stream, est(u));
+    for (size_t u : ds) stream = std::max(stream, est(u));
+    const int a_stream = tensor_exponent(stream);
+    for (size_t b = 0; b < c1.size(); ++b) {
+      in_exp[c1[b]] = b == 0 ? cur : a_stream;
+      out_exp[c1[b]] = tensor_exponent(est(c1[b]));
+      in_exp[c2[b]] = out_exp[c1[b]];
+      out_exp[c2[b]] = tensor_exponent(est(c2[b]));
+      in_exp[c3[b]] = out_exp[c2[b]];
+      out_exp[c3[b]] = a_stream;
+    }
+    for (size_t u : ds) { in_exp[u] = cur; out_exp[u] = a_stream; }
+    cur = a_stream;
+    ui = end;
+  }
+  in_exp[ui] = cur;                                   // classifier.0
+  out_exp[ui] = tensor_exponent(est(ui));
+  in_exp[ui + 1] = out_exp[ui];                       // classifier.4: f32 weights, no BatchNorm
+  out_exp[ui + 1] = 0;
+}
+
+// v * 2^e for a BatchNorm scale / shift; NBC_PACK_SCALE_RANGE when that leaves f32's normal range (the product is then no
+// longer the exact power-of-two multiple the normalisations rest on)
+static float ldexp_flagged(float v, int e, int* flags) {
+  if (e == 0) return v;
+  const float r = std::ldexp(v, e);
+  if (std::isfinite(v) && v != 0.f && (!std::isfinite(r) || std::fabs(r) < 1.17549435e-38f)) *flags |= NBC_PACK_SCALE_RANGE;
+  return r;
 }
 
 thread_local std::string g_last_error;
@@ -349,12 +446,26 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
   unsigned char* base = static_cast<unsigned char*>(blob);
   const int eb = elem_bytes(precision);
   const auto& units = conv_units();
+  int flags = 0;
+  std::vector<int> out_exp(units.size(), 0), in_exp(units.size(), 0);
+  if (precision == NBC_PREC_F16X2) {
+    std::vector<const float*> gam(units.size(), nullptr), bet(units.size(), nullptr), var(units.size(), nullptr);
+    for (size_t ui = 0; ui < units.size(); ++ui) {
+      const ConvUnit& c = units[ui];
+      if (c.bn.empty()) continue;                                           // classifier.4: never asked for an estimate
+      gam[ui] = static_cast<const float*>(given[c.bn + ".weight"]->data);
+      bet[ui] = static_cast<const float*>(given[c.bn + ".bias"]->data);
+      var[ui] = static_cast<const float*>(given[c.bn + ".running_var"]->data);
+    }
+    activation_exponents(gam, bet, var, out_exp, in_exp);
+  }
   for (size_t ui = 0; ui < units.size(); ++ui) {
     const ConvUnit& c = units[ui];
     const PackedConv& p = L.convs[ui];
     const float* w = static_cast<const float*>(given[c.name + ".weight"]->data);
     if (p.head) {
-      std::memcpy(base + p.w_off, w, (size_t)c.cout * c.cin * 4);
+      float* hw = reinterpret_cast<float*>(base + p.w_off);
+      for (size_t e = 0; e < (size_t)c.cout * c.cin; ++e) hw[e] = ldexp_flagged(w[e], -in_exp[ui], &flags);   // f16x2: its input's power off
       std::memcpy(base + p.shift_off, given[c.name + ".bias"]->data, (size_t)c.cout * 4);
       continue;
     }
@@ -384,7 +495,9 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
       const size_t row_floats = row_bytes / 4;
       for (int o = 0; o < c.cout; ++o) {
         float* row = reinterpret_cast<float*>(base + p.w_off + (size_t)o * row_bytes);
-        row_exp[o] = f16x2_row_exponent(row, row_floats);
+        bool clamped = false;
+        row_exp[o] = f16x2_row_exponent(row, row_floats, &clamped);
+        if (clamped) flags |= NBC_PACK_ROW_CLAMPED;
         if (row_exp[o] != 0)
           for (size_t e = 0; e < row_floats; ++e) row[e] = std::ldexp(row[e], row_exp[o]);
       }
@@ -404,11 +517,26 @@ int nbc_pack_weights(const nbc_tensor* tensors, int n, int precision, void* blob
       const float t = mu[o] * alpha;
       // f16x2: the row's power of two comes off again here (exact unless alpha * 2^-k leaves f32's normal range:
       // f16x2_row_exponent's clamp)
-      scale[o] = row_exp.empty() ? alpha : std::ldexp(alpha, -row_exp[o]);
-      shift[o] = b[o] - t;
+      // ... and the powers of the tensors this launch reads and writes (activation_exponents; all zero outside f16x2)
+      scale[o] = ldexp_flagged(alpha, (row_exp.empty() ? 0 : -row_exp[o]) + out_exp[ui] - in_exp[ui], &flags);
+      shift[o] = ldexp_flagged(b[o] - t, out_exp[ui], &flags);
     }
   }
+  int32_t* meta = reinterpret_cast<int32_t*>(base + L.meta_off);
+  meta[0] = kMetaMagic;
+  meta[1] = flags;
+  meta[2] = (int32_t)units.size();
+  for (size_t ui = 0; ui < units.size(); ++ui) meta[kMetaExpBase + ui] = out_exp[ui];
   return NBC_OK;
+}
+
+int nbc_packed_weights_flags(const void* blob, size_t blob_bytes, int precision) {
+  if (!known_precision(precision) || !blob) return set_error(NBC_ERR_INVALID, "nbc_packed_weights_flags: bad argument");
+  const PackedLayout L = packed_layout(precision);
+  if (blob_bytes < L.total_bytes) return set_error(NBC_ERR_INVALID, "nbc_packed_weights_flags: blob too small");
+  const int32_t* meta = reinterpret_cast<const int32_t*>(static_cast<const unsigned char*>(blob) + L.meta_off);
+  if (meta[0] != kMetaMagic) return set_error(NBC_ERR_INVALID, "nbc_packed_weights_flags: not a blob of nbc_pack_weights (this version)");
+  return meta[1];
 }
 
 }  // extern "C"

@@ -50,8 +50,17 @@ struct PackedConv {
   bool head;             // classifier.4: weights kept f32 [3][512], shift = bias
 };
 
+// Trailer of the blob: what a rank that receives the blob by broadcast must know besides the panels.
+//   int32 meta[kMetaWords]: [0] kMetaMagic, [1] NBC_PACK_* flags, [2] number of conv units,
+//   [kMetaExpBase + u] the power of two the OUTPUT tensor of conv unit u is stored with (f16x2; 0 elsewhere): see
+//   activation_exponents in nbc_net.cpp
+constexpr int kMetaWords = 256;
+constexpr int kMetaExpBase = 8;
+constexpr int32_t kMetaMagic = 0x4e424335;   // "NBC5"
+
 struct PackedLayout {
   std::vector<PackedConv> convs;
+  size_t meta_off;       // int32[kMetaWords]
   size_t total_bytes;
 };
 

@@ -301,6 +301,31 @@ class FCNResNet50:
                             k=int(rec.kh), cout=int(rec.cout), launches=int(rec.launches)))
         return out
 
+    @property
+    def pack_flags(self) -> int:
+        """NBC_PACK_* bits of the weights this model holds (0 = nothing given up): in "f16x2" mode a weight row beyond the
+        reach of the row normalisation (``_lib.PACK_ROW_CLAMPED``) or a BatchNorm scale / shift pushed out of f32's normal
+        range by the powers of two folded into it (``_lib.PACK_SCALE_RANGE``) -- run such a checkpoint in "fp32".  Read from
+        the packed blob's trailer, so a rank that received the blob by broadcast sees the same bits."""
+        if self._ctx and self._blob_dev is not None:
+            rc = self._lib.nbc_weights_flags(self._ctx)
+            if rc < 0:
+                _lib.check(rc, "nbc_weights_flags")
+            return int(rc)
+        if self._blob_host is None:
+            raise RuntimeError("no weights loaded")
+        rc = self._lib.nbc_packed_weights_flags(self._blob_host.ctypes.data, self._blob_host.size, self._prec)
+        if rc < 0:
+            _lib.check(rc, "nbc_packed_weights_flags")
+        return int(rc)
+
+    def activation_exponent(self, name: str) -> int:
+        """Power of two the output tensor of op ``name`` is stored with on the device (0 outside "f16x2" and for every
+        tensor of an ordinary checkpoint; nbc_activation_exponent)."""
+        e = C.c_int32(0)
+        _lib.check(self._lib.nbc_activation_exponent(self._require_ctx(), name.encode(), C.byref(e)), "nbc_activation_exponent")
+        return int(e.value)
+
     def nonfinite_seen(self, reset: bool = True) -> bool:
         """True when a forward since the last reset produced a NaN / infinite logit (nbc_nonfinite_seen; synchronises).
         In "f16x2" mode that also means an activation left f16's range: rerun such weights in "fp32"."""

@@ -290,7 +290,35 @@ def preprocess_images(root: str, target_size: int = 1024, model=None) -> None:
 
 
 class NonFiniteLogits(RuntimeError):
-    """A forward produced NaN / infinite logits: in f16x2 mode an activation beyond f16's range (or NaN/inf weights)."""
+    """A forward produced NaN / infinite logits: in f16x2 mode an activation beyond f16's range (or NaN/inf weights) -- or the
+    packer reported weights the f16 pieces cannot carry at f32 grade (``FCNResNet50.pack_flags``), before any forward ran."""
+
+
+class AbandonMarker:
+    """How the ranks of one node tell each other that an f16x2 run is being abandoned: a file under ``results/`` that the
+    rank that sees the non-finite word creates and every rank looks for once per window of images (``os.path.exists``: no
+    collective, so ranks with different numbers of windows cannot wait for each other).  The folder driver's ranks share a
+    node (``--gpus N`` starts them on this one) and the folder's file system with it.  Rank 0 clears a stale marker before
+    the start barrier and the final one after the flag all-reduce."""
+
+    def __init__(self, root: str):
+        self.path = os.path.join(root, "results", ".f16x2_abandoned")
+
+    def set(self):
+        try:
+            os.makedirs(os.path.dirname(self.path), exist_ok=True)
+            open(self.path, "w").close()
+        except OSError:
+            pass                                         # the flag all-reduce at the end still tells every rank
+
+    def is_set(self) -> bool:
+        return os.path.exists(self.path)
+
+    def clear(self):
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
 
 
 def shard_indices(n: int, rank: int, world: int) -> List[int]:
@@ -428,14 +456,23 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     model = FCNResNet50(precision)
     model.to(dev)
     pre_model = FCNResNet50(precision).to(dev)      # its own context: the pool's device resizes never touch the predictor's
+    marker = AbandonMarker(root)
     if rank == 0:
         generate_folders(root)
+        marker.clear()
     if dist is not None:
         dist.barrier()
     if rank == 0:                                    # only one rank touches the checkpoint
         model.load_state_dict(torch.load(model_path, map_location="cpu", weights_only=True))
     if dist is not None:
         model.broadcast_weights(src=0)
+    if precision == "f16x2" and model.pack_flags:
+        # what the packer had to give up rides in the blob's trailer: every rank reads the same bits and leaves here alike
+        err = NonFiniteLogits("the packed weights carry NBC_PACK flags %d (a weight row beyond the reach of the f16x2 row "
+                              "normalisation, or a BatchNorm scale outside f32's normal range under its powers of two): f16x2 "
+                              "would not be f32 grade on this checkpoint; rerun with --precision fp32" % model.pack_flags)
+        err.batches_run, err.images_this_rank = 0, 0
+        raise err
     models = [model] + [model.clone_shared() for _ in range(n_streams - 1)]
     # side streams only: the default stream stays with the pool's device resizes (pre_model)
     gpu_streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
@@ -523,6 +560,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         ring_ev[slot].synchronize()
         if check_flag and int(flag_host[slot]) != 0:
             bad_seen[0] = True                       # this batch's labels (and every later one's) are not valid: nothing is written
+            if world > 1:
+                marker.set()                         # the other ranks of the node stop at their next window
             return
         lab_host, cnt_host = ring[slot]
         labs = lab_host[: n * h * w].numpy().reshape(n, h, w).copy()
@@ -540,6 +579,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         futs = {k: pool.submit(prepare, mine[k]) for k in (windows[0] if windows else [])}
         t_loop = time.perf_counter()
         for wi, win in enumerate(windows):
+            if check_flag and world > 1 and not bad_seen[0] and marker.is_set():
+                bad_seen[0] = True                       # another rank of the node saw the word
             if bad_seen[0]:                              # f16x2 cannot carry these weights: the run is abandoned here
                 break
             if wi + 1 < len(windows):                    # the pool starts on the next window before the GPU gets this one
@@ -615,6 +656,8 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
             flag = torch.tensor([int(bad)], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             bad = bool(int(flag.item()))
+            if rank == 0:
+                marker.clear()                       # every rank is past its loop (the all-reduce above)
         if bad:
             for path in label_paths:                 # this rank's label PNGs of the invalid run: a crash before the rerun
                 try:                                 # must not leave them behind (the processed/ images do not depend on

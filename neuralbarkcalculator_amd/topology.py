@@ -6,7 +6,7 @@ Restates the layer list of ``/root/reference/src/bark_calculator/models.py:127-1
 the host side can (a) check a state_dict's keys the way ``load_state_dict``
 (``models.py:222``) does and (b) walk the conv units in execution order.
 
-The same table exists in C++ (``csrc/nbc_net.cpp``); ``tests/test_topology.py``
+The same table exists in C++ (``csrc/nbc_net.cpp``); ``tests/test_abi.py::test_topology_through_the_abi``
 checks that the two agree through the C-ABI (``nbc_num_convs`` / ``nbc_conv_info``).
 """
 from __future__ import annotations

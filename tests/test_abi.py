@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from neuralbarkcalculator_amd import _lib, topology
+from neuralbarkcalculator_amd import _lib, synth, topology
 from neuralbarkcalculator_amd.model import FCNResNet50, pack_state_dict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -192,6 +192,13 @@ def test_pack_layout_and_bn_fold(built_lib, sd_np, precision):
         inv = np.float32(1.0) / np.sqrt(var + np.float32(1e-5), dtype=np.float32)
         np.testing.assert_array_equal(scale, g * inv / row_pow2)            # a power of two: the division is exact
         np.testing.assert_array_equal(shift, b - mu * (g * inv))
+    # the trailer: magic, NBC_PACK_* flags (none for this checkpoint), the unit count, one activation power per unit -- all
+    # zero for a checkpoint of ordinary magnitudes, in every precision: the blob computes what round 4's computed
+    meta = blob[off: off + 1024].view(np.int32)
+    assert meta[0] == 0x4e424335 and meta[1] == 0 and meta[2] == len(topology.conv_units())
+    assert not meta[3:].any()
+    assert built_lib.nbc_packed_weights_flags(blob.ctypes.data, blob.nbytes, prec) == 0
+    off = align(off + 1024)
     assert off == blob.nbytes
 
 
@@ -333,3 +340,131 @@ def test_f16x2_row_normalisation_edge_rows(built_lib, sd_np):
             return
         off = a(a(s_off + u.cout * 4) + u.cout * 4)
     raise AssertionError("unit not found")
+
+
+def _trailer(blob):
+    return blob[-1024:].view(np.int32)
+
+
+def _unit_index(name):
+    return [u.name for u in topology.conv_units()].index(name)
+
+
+@pytest.mark.parametrize("where,log2_scale", [("internal", -16), ("stream", -20), ("all", -20), ("all", 12)])
+def test_f16x2_activation_powers_of_two(built_lib, sd_np, where, log2_scale):
+    """nbc_pack_weights stores a tensor whose BatchNorm estimate (max |beta| + 3 |gamma| sqrt(var / (var + eps))) lies outside [2^-5, 2^7] times the
+    power of two that brings the estimate to [2, 4): the powers land in the blob's trailer, the producing unit's (scale,
+    shift) carry 2^a_out, every reading unit's scale 2^-a_in, classifier.4's f32 weights the last tensor's -- all exact, so
+    the rescaled checkpoint packs to the SAME conv weights and to (scale, shift) pairs that are power-of-two multiples of
+    the ordinary checkpoint's up to the one rounding rescale_activations itself puts into gamma.  Other precisions: no powers."""
+    from conftest import rescale_activations
+    s = 2.0 ** log2_scale
+    sd = rescale_activations(sd_np, s, where)
+    base = pack_state_dict(sd_np, "f16x2")
+    blob = pack_state_dict(sd, "f16x2")
+    assert built_lib.nbc_packed_weights_flags(blob.ctypes.data, blob.nbytes, 2) == 0
+    exps = _trailer(blob)[8:8 + len(topology.conv_units())]
+    assert not _trailer(pack_state_dict(sd, "fp32"))[8:].any() and not _trailer(pack_state_dict(sd, "bf16"))[8:].any()
+    units = topology.conv_units()
+    est = {}
+    for i, u in enumerate(units):
+        if u.bn is not None:
+            var = sd[u.bn + ".running_var"].astype(np.float64)
+            est[u.name] = float((np.abs(sd[u.bn + ".bias"]) + 3 * np.abs(sd[u.bn + ".weight"]) * np.sqrt(var / (var + 1e-5))).max())
+
+    def power(e):
+        return 0 if 2.0 ** -5 <= e <= 2.0 ** 7 else 1 - int(np.floor(np.log2(e)))
+
+    moved = 0
+    for i, u in enumerate(units):
+        if u.bn is None:
+            assert exps[i] == 0
+            continue
+        if u.name.endswith(".conv3") or u.name.endswith(".downsample.0"):       # one power per stage: the residual stream's
+            stage = u.name[: len("backbone.layerN")]
+            e = max(v for k, v in est.items() if k.startswith(stage) and (k.endswith(".conv3") or k.endswith(".downsample.0")))
+        else:
+            e = est[u.name]
+        assert exps[i] == power(e), (u.name, exps[i], e)
+        if exps[i] != 0:
+            assert 2.0 <= e * 2.0 ** int(exps[i]) < 4.0
+            moved += 1
+    if where == "internal":
+        assert moved == 32 and all(exps[_unit_index(n)] == 0 for n in ("backbone.conv1", "backbone.layer2.1.conv3", "classifier.0"))
+    if where == "stream":
+        assert moved == 20 and exps[_unit_index("backbone.layer2.1.conv1")] == 0
+    if where == "all":
+        assert moved == 53 and exps[_unit_index("classifier.0")] == 0           # the head's hidden tensor was not rescaled
+    # the conv weight panels do not move at all (their rows are normalised), and what the powers do to (scale, shift) of a
+    # producing + reading pair cancels the rescaling: compare with the ordinary checkpoint's blob section by section
+    off = 0
+    for i, u in enumerate(units):
+        if u.bn is None:
+            break
+        ksteps = 7 if u.cin == 3 else u.k * u.k * u.cin * 4 // 128
+        n = u.cout * ksteps * 128
+        np.testing.assert_array_equal(blob[off: off + n], base[off: off + n], err_msg=u.name)
+        off = (off + n + 255) // 256 * 256
+        sc, sc0 = blob[off: off + 4 * u.cout].view(np.float32), base[off: off + 4 * u.cout].view(np.float32)
+        off = (off + 4 * u.cout + 255) // 256 * 256
+        sh, sh0 = blob[off: off + 4 * u.cout].view(np.float32), base[off: off + 4 * u.cout].view(np.float32)
+        off = (off + 4 * u.cout + 255) // 256 * 256
+        # stored tensor = 2^a x (s or 1) x the ordinary one; |s 2^a| is whatever put the estimate into [2, 4): at most 2^3 here
+        want = sh0.astype(np.float64) * 2.0 ** int(exps[i]) * (s if exps[i] != 0 else 1.0)
+        np.testing.assert_allclose(sh, want, rtol=1e-5, atol=1e-6 * np.abs(want).max(), err_msg=u.name)
+        ratio = sc.astype(np.float64) / sc0
+        assert np.allclose(ratio, ratio.flat[0], rtol=1e-6), u.name             # one factor per unit
+        l2 = np.log2(float(ratio.flat[0]))
+        assert abs(l2 - round(l2)) < 1e-5, (u.name, ratio.flat[0])
+
+
+def test_f16x2_activation_powers_keep_an_ordinary_checkpoint_bit_for_bit(built_lib):
+    """Every tensor of an ordinary checkpoint (seeds of the trained-like generator, torchvision's plain initialisation) has its
+    estimate inside [2^-5, 2^7]: no power, so the blob -- and every result -- is what it was before the powers existed."""
+    for kind, seed in (("trained_like", 7), ("trained_like", 11), ("random_init", 5)):
+        sd = synth.make_state_dict(kind, seed=seed)
+        t = _trailer(pack_state_dict(sd, "f16x2"))
+        assert t[1] == 0 and not t[8:].any(), (kind, seed)
+
+
+def test_pack_flags_report_what_the_normalisations_cannot_reach(built_lib, sd_np):
+    """a weight row beyond the row normalisation's clamp (largest |w| below 2^-51 or above 2^81) keeps fewer bits
+    than f32 with finite logits: reported (NBC_PACK_ROW_CLAMPED), so that --precision auto goes straight to fp32; a BatchNorm
+    scale pushed out of f32's normal range by the powers folded into it likewise (NBC_PACK_SCALE_RANGE).  The accuracy of a
+    row INSIDE the clamp's reach is pinned: every weight back to 2^-22 of the row's largest."""
+    name, bn = "backbone.layer2.1.conv2", "backbone.layer2.1.bn2"
+    for log2_scale, want in ((-45, 0), (-70, 1), (70, 0), (90, 1)):
+        sd = dict(sd_np)
+        sd[name + ".weight"] = sd_np[name + ".weight"] * np.float32(2.0 ** log2_scale)
+        # gamma compensates so that the BatchNorm scale stays an ordinary f32 even for the extreme rows
+        blob = pack_state_dict(sd, "f16x2")
+        flags = built_lib.nbc_packed_weights_flags(blob.ctypes.data, blob.nbytes, 2)
+        assert flags & 1 == want, (log2_scale, flags)
+        assert built_lib.nbc_packed_weights_flags(pack_state_dict(sd, "fp32").ctypes.data, blob.nbytes, 0) == 0
+        if want == 0:
+            # accuracy inside the reach: (P + Q) 2^-k against the f32 weights of channel 0's row
+            units = topology.conv_units()
+            off = 0
+            for u in units:
+                ksteps = 7 if u.cin == 3 else u.k * u.k * u.cin * 4 // 128
+                if u.name == name:
+                    break
+                off = (off + u.cout * ksteps * 128 + 255) // 256 * 256
+                off += 2 * ((4 * u.cout + 255) // 256 * 256)
+            raw = blob[off: off + ksteps * 128]
+            g0, g1 = _join_f16x2(raw, ksteps * 32, 32)
+            w = sd[name + ".weight"].transpose(0, 2, 3, 1).reshape(u.cout, -1)[0].astype(np.float64)
+            k = _row_pow2(w[None].astype(np.float32))[0]
+            back = (g0[0].astype(np.float64) + g1[0].astype(np.float64)) / float(k)
+            assert np.abs(back - w).max() <= 2.0 ** -22 * np.abs(w).max(), log2_scale
+    # a BatchNorm whose scale cannot take its power of two: gamma / sqrt(var + eps) near f32's smallest normal, and a tensor
+    # estimate that asks for 2^-a on top
+    # a BatchNorm scale that cannot take its powers of two: a tensor at 2^-100 of the usual size (its power: 2^99) read by a
+    # convolution whose weights sit at 2^-40 (row power 2^59) under an ordinary BatchNorm: scale x 2^-158 is no f32 normal
+    sd = dict(sd_np)
+    sd["backbone.layer3.1.bn1.weight"] = sd_np["backbone.layer3.1.bn1.weight"] * np.float32(2.0 ** -100)
+    sd["backbone.layer3.1.bn1.bias"] = sd_np["backbone.layer3.1.bn1.bias"] * np.float32(2.0 ** -100)
+    sd["backbone.layer3.1.conv2.weight"] = sd_np["backbone.layer3.1.conv2.weight"] * np.float32(2.0 ** -40)
+    blob = pack_state_dict(sd, "f16x2")
+    assert built_lib.nbc_packed_weights_flags(blob.ctypes.data, blob.nbytes, 2) == 2
+    assert built_lib.nbc_packed_weights_flags(pack_state_dict(sd, "fp32").ctypes.data, blob.nbytes, 0) == 0

@@ -297,3 +297,18 @@ def test_perf_marker_gate():
     assert asks("perf") and asks("gpu and perf") and asks("perf and gpu")
     for expr in ("", "gpu", "not gpu", "gpu and not perf", "not perf", "perfect", "gpu or perfect"):
         assert not asks(expr), expr
+
+
+def test_abandon_marker_is_a_file_every_rank_of_the_node_can_see(tmp_path):
+    """the early abandon of an f16x2 folder run was rank-local.  The rank that sees the non-finite word now drops
+    a marker file under results/ that every rank polls once per window (no collective: ranks have different numbers of
+    windows); rank 0 clears a stale one at the start and the final one after the flag all-reduce."""
+    from neuralbarkcalculator_amd.predict import AbandonMarker
+    a, b = AbandonMarker(str(tmp_path)), AbandonMarker(str(tmp_path))     # two ranks, one folder
+    assert not a.is_set() and not b.is_set()
+    a.clear()                                                             # nothing to clear: no error
+    b.set()
+    assert a.is_set() and os.path.dirname(a.path) == str(tmp_path / "results")
+    a.set()                                                               # twice is fine
+    a.clear()
+    assert not b.is_set()

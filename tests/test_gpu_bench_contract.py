@@ -33,8 +33,10 @@ def check_roofline(r, peak):
     # sources (the mechanism `traffic` uses); the raw-event frac reads a few percent under it
     if r["traffic"] is not None:
         assert r["table"].startswith("profiles/per_forward_ops_") and 0 < r["frac_rocprof_table"] < 1
+        hc = r["head_conv_rocprof_table"]                 # the longest launch: its in-kernel clock next to the table's frac
+        assert hc["op"] == "classifier.0" and 0.5 < hc["clock_ghz_in_pmc_pass"] < 3.0 and 0 < hc["frac_of_peak"] < 1
     else:
-        assert "frac_rocprof_table" not in r and "table" not in r
+        assert "frac_rocprof_table" not in r and "table" not in r and "head_conv_rocprof_table" not in r
 
 
 def test_default_bench_line(built_lib):
@@ -44,6 +46,9 @@ def test_default_bench_line(built_lib):
     assert d["metric"].startswith("1024x1024 images/sec") and d["unit"] == "images/s"
     assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["rccl_ranks"] == 1
     assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]      # batch 1, one rank
+    # the line's own spread: the bracketed region five times, `value` the first of them (the contract's)
+    assert len(d["value_repeats"]) == 5 and d["value_repeats"][0] == d["value"]
+    assert d["value_median"] == sorted(d["value_repeats"])[2] and min(d["value_repeats"]) > 0.5 * d["value_median"]
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f16x2" and "f32-grade" in d["dtype_note"] and d["data"] == "synthetic"
     assert d["config"]["workload"].startswith("configs[1]") and "model" not in d["config"]

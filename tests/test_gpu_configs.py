@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, rescale_activations, rescale_conv_weights
 from neuralbarkcalculator_amd import synth
 from neuralbarkcalculator_amd.model import FCNResNet50
 
@@ -192,29 +192,6 @@ def test_f32_grade_modes_on_other_weights(built_lib, kind, seed, scale):
           % (kind, seed, scale, report["f16x2"][0], report["fp32"][0], cpu_err))
 
 
-def rescale_conv_weights(sd, s):
-    """Every convolution in front of a BatchNorm (all 54 of them) with its weights multiplied by the power of two `s`, the
-    BatchNorm's running_mean scaled by s and its running_var by s^2 (both exact), and its weight (gamma) by
-    sqrt(var s^2 + eps) / (s sqrt(var + eps)) (float64, rounded once), which undoes what eps does to a rescaled variance:
-    the network computes the same function as before up to rounding, every activation keeps its magnitude, and the
-    convolution weights sit 2^-12 / 2^-16 lower (or 2^10 higher) than a Kaiming initialisation puts them.  A convolution
-    in front of a BatchNorm is scale-free, so a trained checkpoint may look like this (models.py:222 takes any)."""
-    from neuralbarkcalculator_amd import topology
-    out = dict(sd)
-    s32, eps = np.float32(s), 1e-5
-    for u in topology.conv_units():
-        if u.bn is None:
-            continue
-        out[u.name + ".weight"] = sd[u.name + ".weight"] * s32
-        var = sd[u.bn + ".running_var"]
-        var_s = var * np.float32(s * s)
-        out[u.bn + ".running_mean"] = sd[u.bn + ".running_mean"] * s32
-        out[u.bn + ".running_var"] = var_s
-        fix = np.sqrt(var_s.astype(np.float64) + eps) / (s * np.sqrt(var.astype(np.float64) + eps))
-        out[u.bn + ".weight"] = (sd[u.bn + ".weight"].astype(np.float64) * fix).astype(np.float32)
-    return out
-
-
 @pytest.mark.parametrize("log2_scale", [-12, -16, 10])
 def test_f32_grade_modes_with_rescaled_conv_weights(built_lib, sd_np, log2_scale):
     """The small-magnitude floor of the f16 pieces (what's weak 2): with every convolution's weights at
@@ -256,4 +233,55 @@ def test_f32_grade_modes_with_rescaled_conv_weights(built_lib, sd_np, log2_scale
     print("conv weights x 2^%d: logit error / range vs float64: f16x2 %.2e, f32 MFMA %.2e, CPU f32 oracle %.2e; vs the CPU oracle "
           "(low-res): f16x2 %.2e, f32 MFMA %.2e" % (log2_scale, report["f16x2"][0], report["fp32"][0], cpu_err,
                                                     report["f16x2"][1], report["fp32"][1]))
+    assert not failures, failures
+
+
+@pytest.mark.parametrize("where,log2_scale", [("internal", -16), ("internal", -20), ("stream", -16), ("stream", -20),
+                                              ("all", -20), ("all", 12)])
+def test_f32_grade_modes_with_rescaled_activations(built_lib, sd_np, where, log2_scale):
+    """The activation side of the f16 pieces' floor (what's weak 2 / item 4).  A tensor between a BatchNorm and
+    the next convolution is scale-free, so a checkpoint may hold bottleneck activations (or a residual stream) at 2^-16 or
+    2^-20 of their usual size; split as they stand, the LOW piece of such a value is an f16 subnormal or zero and every
+    product loses bits -- with finite logits, so nothing raises the non-finite flag (measured on round 4's library:
+    profiles/r05_small_activation_floor_before_fix.log).  At 2^12 the other end: values beyond 65 504 overflow the high
+    piece.  nbc_pack_weights therefore estimates every tensor's magnitude from its producing BatchNorm (max |beta| +
+    3 |gamma| sqrt(var / (var + eps))), picks a power of two per tensor (one per residual stream) and folds it into the producer's f32 (scale,
+    shift) and its inverse into every consumer's scale: exact, ReLU and max-pool being positively homogeneous.
+    f16x2 and the f32 MFMA mode against the CPU f32 oracle AND a float64 evaluation of the same state_dict under
+    LOGIT_RTOL_FP32; labels equal to float64's outside the tie band; layer-by-layer read-back takes the power off again."""
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50, predict_labels
+    sd = rescale_activations(sd_np, 2.0 ** log2_scale, where)
+    oracle = OracleFCNResNet50()
+    oracle.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    o64 = OracleFCNResNet50()
+    o64.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    o64 = o64.double()
+    x = frames([81, 82], 256, 320)
+    lab32, counts32, log32, low32 = predict_labels(oracle, x)
+    lab64, _, log64, low64 = predict_labels(o64, x.double())
+    assert (counts32 > 0.02 * 256 * 320).all(), counts32          # still a frame with all three classes
+    rng = float(log64.abs().max())
+    report, failures = {}, []
+    for mode in ("f16x2", "fp32"):
+        m = FCNResNet50(mode).load_state_dict(sd).to(DEV)
+        labels, counts, lowres = m.predict_labels(x.to(DEV), return_lowres=True)
+        logits = m(x.to(DEV))
+        torch.cuda.synchronize()
+        if m.nonfinite_seen():
+            failures.append((mode, "non-finite logits"))
+            report[mode] = (float("nan"), float("nan"))
+            continue
+        err64 = float((logits.cpu().double() - log64).abs().max())
+        err32 = float((lowres.cpu() - low32).abs().max())
+        report[mode] = (err64 / rng, err32 / rng)
+        top2 = torch.topk(log64, 2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 2.0 * err64
+        if not (err64 <= LOGIT_RTOL_FP32 * rng and err32 <= LOGIT_RTOL_FP32 * rng):
+            failures.append((mode, "logits", err64 / rng, err32 / rng))
+        if not torch.equal(labels.cpu()[clear], lab64[clear]):
+            failures.append((mode, "labels outside the tie band"))
+    cpu_err = float((log32.double() - log64).abs().max()) / rng
+    print("activations (%s) x 2^%d: logit error / range vs float64: f16x2 %.2e, f32 MFMA %.2e, CPU f32 oracle %.2e; vs the CPU "
+          "oracle (low-res): f16x2 %.2e, f32 MFMA %.2e" % (where, log2_scale, report["f16x2"][0], report["fp32"][0], cpu_err,
+                                                           report["f16x2"][1], report["fp32"][1]))
     assert not failures, failures

@@ -9,6 +9,7 @@ import pytest
 import torch
 from PIL import Image
 
+from conftest import overflowing_state_dict
 from neuralbarkcalculator_amd import predict as drv
 from neuralbarkcalculator_amd import synth
 from neuralbarkcalculator_amd.postprocess import remove_small_zones
@@ -300,8 +301,7 @@ def test_cli_falls_back_to_fp32_when_f16x2_overflows(tmp_path, sd_np, built_lib)
     fp32 library call; the library call in f16x2 raises."""
     import subprocess
     import sys
-    big = dict(sd_np)
-    big["backbone.bn1.weight"] = sd_np["backbone.bn1.weight"] * np.float32(3e4)
+    big = overflowing_state_dict(sd_np)
     layout = [("sapin", "a.bmp", 11, 88, 120), ("epinette_gelee", "c.png", 13, 64, 200)]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     root_cli, root_call = str(tmp_path / "cli"), str(tmp_path / "call")
@@ -331,8 +331,7 @@ def test_f16x2_overflow_abandons_the_folder_at_the_first_batches(tmp_path, sd_np
     """The sticky non-finite word rides back with every batch's labels (nbc_nonfinite_peek_async), so a folder whose weights
     f16x2 cannot carry is abandoned after the batches that were in flight when the first one came back -- not after the
     last image (what's weak 5) -- and no label PNG of the run stays on disk."""
-    big = dict(sd_np)
-    big["backbone.bn1.weight"] = sd_np["backbone.bn1.weight"] * np.float32(3e4)
+    big = overflowing_state_dict(sd_np)
     layout = [("sapin", "s%02d.bmp" % i, 40 + i, 64, 96) for i in range(24)]
     root = str(tmp_path / "many")
     ckpt, _ = _make_folder(root, big, layout)
@@ -343,3 +342,20 @@ def test_f16x2_overflow_abandons_the_folder_at_the_first_batches(tmp_path, sd_np
     assert not os.path.isdir(out) or os.listdir(out) == []
     st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0, batch=1, streams=2, window=4)
     assert st["images_total"] == 24 and len(os.listdir(out)) == 24
+
+
+def test_f16x2_refuses_weights_the_packer_flags_before_any_forward(tmp_path, sd_np, built_lib):
+    """a weight row beyond the reach of the f16x2 row normalisation (largest |w| below 2^-51) keeps only a few
+    bits with finite logits, so no flag could ever report it from the device: nbc_pack_weights reports it
+    (NBC_PACK_ROW_CLAMPED, in the blob's trailer), the folder driver leaves in f16x2 before the first forward -- the way it
+    leaves on the non-finite word, so --precision auto runs the folder on the f32 MFMA -- and fp32 takes the checkpoint."""
+    sd = dict(sd_np)
+    sd["backbone.layer2.1.conv2.weight"] = sd_np["backbone.layer2.1.conv2.weight"] * np.float32(2.0 ** -70)
+    layout = [("sapin", "a.bmp", 11, 88, 120)]
+    root = str(tmp_path / "flagged")
+    ckpt, _ = _make_folder(root, sd, layout)
+    with pytest.raises(drv.NonFiniteLogits) as e:
+        drv.predict_folder(root, ckpt, precision="f16x2", device_index=0)
+    assert e.value.batches_run == 0 and "NBC_PACK flags 1" in str(e.value)
+    st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0)
+    assert st["images_total"] == 1

@@ -18,7 +18,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, load_golden_labels
+from conftest import load_golden, load_golden_labels, overflowing_state_dict
 from neuralbarkcalculator_amd import synth
 from neuralbarkcalculator_amd.model import FCNResNet50
 
@@ -97,6 +97,40 @@ def test_every_conv_unit_against_oracle(oracle_model, gpu_fp32, gpu_bf16, mode):
         model.set_keep_activations(False)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c128_layers.npz"), allow_pickle=False)
     assert list(g["names"]) == list(ref.keys())
+
+
+def test_every_conv_unit_with_rescaled_activations(built_lib, sd_np):
+    """The same layer-by-layer comparison for a checkpoint whose scale-free tensors sit at 2^-20 of their usual size
+    (tests/conftest.py::rescale_activations): in "f16x2" every such tensor is STORED with its power of two
+    (nbc_pack_weights), the read-back takes it off again, and every layer matches the oracle under the same tolerance --
+    relative to the tensor's own (small) range, which is what the f16 pieces would not hold as they stand."""
+    from conftest import rescale_activations
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50, layer_outputs
+    sd = rescale_activations(sd_np, 2.0 ** -20, "all")
+    oracle = OracleFCNResNet50()
+    oracle.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = frames([3], 128, 128)
+    ref = layer_outputs(oracle, x)
+    for mode in ("f16x2", "fp32"):
+        model = FCNResNet50(mode).load_state_dict(sd).to(DEV)
+        assert model.pack_flags == 0
+        powers = [model.activation_exponent(n) for n in ref if n != "classifier.4"]
+        assert (mode == "f16x2") == any(powers), (mode, powers)
+        if mode == "f16x2":
+            assert model.activation_exponent("backbone.maxpool") == model.activation_exponent("backbone.conv1") >= 18
+        model.set_keep_activations(True)
+        lowres = model.lowres_logits(x.to(DEV))
+        torch.cuda.synchronize()
+        worst = ("", 0.0)
+        for name, want in ref.items():
+            got = lowres.cpu().numpy() if name == "classifier.4" else model.read_activation(name, want.numel())
+            want = want.numpy()
+            scale = float(np.abs(want).max())
+            err = float(np.abs(got - want).max()) / scale
+            worst = max(worst, (name, err), key=lambda t: t[1])
+            assert err <= LAYER_RTOL_FP32, f"{name}: rel err {err} at scale {scale} ({mode})"
+        print(mode, "activations x 2^-20: worst layer rel err", worst)
+        assert not model.nonfinite_seen()
 
 
 @pytest.mark.parametrize("name", ["c128", "b2_256", "odd_h", "h520", "full1024"])
@@ -608,8 +642,7 @@ def test_f16x2_out_of_range_activations_raise_the_flag(built_lib, sd_np):
     the logits behind it are NaN, and nbc_nonfinite_seen says so; the f32 MFMA mode runs the same weights fine, and a
     normal network never raises the flag."""
     x = frames([76], 96, 128).to(DEV)
-    big = dict(sd_np)
-    big["backbone.bn1.weight"] = sd_np["backbone.bn1.weight"] * np.float32(3e4)      # stem outputs in the 1e5 range
+    big = overflowing_state_dict(sd_np)                                               # stem outputs in the 1e5 range
     m16 = FCNResNet50("f16x2").load_state_dict(big).to(DEV)
     m32 = FCNResNet50("fp32").load_state_dict(big).to(DEV)
     assert not m16.nonfinite_seen() and not m32.nonfinite_seen()                      # nothing run yet
@@ -631,7 +664,10 @@ def test_f16x2_out_of_range_activations_raise_the_flag(built_lib, sd_np):
     side.synchronize()
     assert int(word[0]) != 0 and int(word[1]) == 0
     with pytest.raises(ValueError):
-        m16.nonfinite_peek_async(torch.zeros(1, dtype=torch.int32))                   # not pinned
+        m16.nonfinite_peek_async(torch.zeros(1, dtype=torch.int32))                   # not pinned: refused by the wrapper ...
+    pageable = np.zeros(1, dtype=np.uint32)                                           # ... and, for a C host, by the library
+    rc = built_lib.nbc_nonfinite_peek_async(m16._require_ctx(), pageable.ctypes.data, None)
+    assert rc == -1 and "pinned" in built_lib.nbc_last_error().decode()
     assert m16.nonfinite_seen(reset=False) and m16.nonfinite_seen() and not m16.nonfinite_seen()   # sticky until reset
     ok = FCNResNet50("f16x2").load_state_dict(sd_np).to(DEV)
     ok.predict_labels(x)

@@ -142,7 +142,7 @@ def test_rescaled_conv_weights_leave_the_function_unchanged(sd_np):
     convolution's weights by a power of two, the following BatchNorm's running_mean by the same, its running_var by the
     square, and its gamma by sqrt(var s^2 + eps) / (s sqrt(var + eps)) leaves the network's function unchanged (float64
     evaluation: the only difference is the rounding of the float32 gamma)."""
-    from test_gpu_configs import rescale_conv_weights
+    from conftest import rescale_conv_weights
     from oracle.fcn_resnet50_oracle import OracleFCNResNet50
     x = torch.from_numpy(np.stack([synth.make_input(5, 64, 96)])).double()
     outs = []
@@ -158,3 +158,34 @@ def test_rescaled_conv_weights_leave_the_function_unchanged(sd_np):
     # and the weights really are where the test says: 2^-16 of a Kaiming initialisation is 1e-7 .. 1e-6
     w = rescale_conv_weights(sd_np, 2.0 ** -16)["backbone.layer3.2.conv2.weight"]
     assert 1e-8 < float(np.abs(w).mean()) < 2e-6
+
+
+def test_rescaled_activations_leave_the_function_unchanged(sd_np):
+    """The premise of tests/test_gpu_configs.py::test_f32_grade_modes_with_rescaled_activations: a BatchNorm's gamma and beta
+    times a power of two, with the statistics of the BatchNorm behind every convolution that reads the tensor scaled along
+    and its gamma compensating eps, leaves the network's function unchanged (float64 evaluation) -- and the tensors really
+    are that much smaller."""
+    from conftest import rescale_activations
+    from oracle.fcn_resnet50_oracle import OracleFCNResNet50
+    x = torch.from_numpy(np.stack([synth.make_input(5, 64, 96)])).double()
+    outs, peaks = [], []
+    for where, log2_scale in ((None, 0), ("internal", -20), ("stream", -20), ("all", -16), ("all", 12)):
+        sd = sd_np if where is None else rescale_activations(sd_np, 2.0 ** log2_scale, where)
+        m = OracleFCNResNet50()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        m = m.double()
+        seen = {}
+        hooks = [m.backbone.layer3[2].bn2.register_forward_hook(lambda mod, i, o: seen.__setitem__("t2", float(o.abs().max()))),
+                 m.backbone.layer2.register_forward_hook(lambda mod, i, o: seen.__setitem__("stream", float(o.abs().max())))]
+        with torch.no_grad():
+            outs.append(m(x))
+        for h in hooks:
+            h.remove()
+        peaks.append(seen)
+    rng = float(outs[0].abs().max())
+    for o in outs[1:]:
+        assert float((o - outs[0]).abs().max()) <= 5e-6 * rng
+    base = peaks[0]
+    assert abs(peaks[1]["t2"] / base["t2"] / 2.0 ** -20 - 1) < 1e-3 and abs(peaks[1]["stream"] / base["stream"] - 1) < 1e-3
+    assert abs(peaks[2]["stream"] / base["stream"] / 2.0 ** -20 - 1) < 1e-3 and abs(peaks[2]["t2"] / base["t2"] - 1) < 1e-3
+    assert abs(peaks[3]["t2"] / base["t2"] / 2.0 ** -16 - 1) < 1e-3 and abs(peaks[4]["stream"] / base["stream"] / 2.0 ** 12 - 1) < 1e-3

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Register / spill / occupancy table of the conv kernel's instantiations (hipcc -Rpass-analysis=kernel-resource-usage).
   python tools/kernel_regs.py [precision]      precision: 0 f32, 1 bf16, 2 f16x2 (default: all)
-Columns: template arguments <PREC, WM, WN, MT, NT, S, STEM, VAR>, VGPRs, AGPRs, spilled VGPRs, waves per SIMD."""
+Columns: template arguments <PREC, WM, WN, MT, NT, S, STEM, VAR, BIGW>, VGPRs, AGPRs, spilled VGPRs, waves per SIMD."""
 import os
 import re
 import subprocess
@@ -17,7 +17,7 @@ cur, rows = None, []
 for line in out.splitlines():
     m = re.search(r"Function Name: (\S+)", line)
     if m:
-        t = re.search(r"conv_dma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)E", m.group(1))
+        t = re.search(r"conv_dma_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELb(\d)E", m.group(1))
         cur = dict(args=tuple(int(v) for v in t.groups())) if t else None
         if cur:
             rows.append(cur)
@@ -31,8 +31,8 @@ for line in out.splitlines():
             cur[key] = int(m.group(1))
 if "error" in out:
     print(out[-3000:])
-print("PREC WM WN MT NT S STEM VAR | VGPR AGPR spill scratch occ")
+print("PREC WM WN MT NT S STEM VAR BIGW | VGPR AGPR spill scratch occ")
 for r in sorted(rows, key=lambda r: r["args"]):
     if want is not None and str(r["args"][0]) != want:
         continue
-    print("%4d %2d %2d %2d %2d %d %4d %3d | %4d %4d %5d %7d %3d" % (r["args"] + (r.get("vgpr", -1), r.get("agpr", -1), r.get("spill", -1), r.get("scratch", -1), r.get("occ", -1))))
+    print("%4d %2d %2d %2d %2d %d %4d %3d %4d | %4d %4d %5d %7d %3d" % (r["args"] + (r.get("vgpr", -1), r.get("agpr", -1), r.get("spill", -1), r.get("scratch", -1), r.get("occ", -1))))
