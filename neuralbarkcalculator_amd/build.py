@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libnbc_hip.so")
-SOURCES = ["nbc_net.cpp", "conv_igemm_dma.hip", "pointwise.hip", "small_zones.hip", "nbc_api.hip"]
+SOURCES = ["nbc_net.cpp", "conv_igemm_dma.hip", "conv3x3_rows.hip", "pointwise.hip", "small_zones.hip", "nbc_api.hip"]
 ARCH = "gfx950"
 
 
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _deps_newer(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs

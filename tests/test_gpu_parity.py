@@ -133,6 +133,44 @@ def test_every_conv_unit_with_rescaled_activations(built_lib, sd_np):
         assert not model.nonfinite_seen()
 
 
+@pytest.mark.parametrize("shape", [(1, 72, 1024), (2, 40, 1024), (1, 8, 1024), (3, 24, 1024)])
+def test_row_resident_3x3_kernel_layer_by_layer(oracle_model, built_lib, sd_np, shape):
+    """The 3x3 layers of a 1024-pixel-wide image (128-pixel-wide maps from layer2 on) with 256 output channels or more --
+    layer3 / layer4 conv2 at dilation 1, 2 and 4 and classifier.0 -- run in "f16x2" on the row-resident kernel
+    (csrc/conv3x3_rows.hip: a pixel row fetched once for the three taps of a kernel row, K order (channel block, kh, kw)).
+    Every conv unit against the oracle under the layer tolerance on shapes that exercise its edges: an odd number of map rows
+    (the two-row tile's tail), batches whose images share a tile (row 2k+1 of image 0 with row 0 of image 1), a map of ONE
+    row (every dilated tap row outside the image), and its two tiles (18: one image row per block; 19: two) against the
+    default choice bit for bit -- the K order is the layer's, not the tile's."""
+    from oracle.fcn_resnet50_oracle import layer_outputs
+    n, h, w = shape
+    x = frames(range(30, 30 + n), h, w)
+    ref = layer_outputs(oracle_model, x)
+    m = FCNResNet50("f16x2").load_state_dict(sd_np).to(DEV)
+    m.set_keep_activations(True)
+    lows = {}
+    for tile in (-1, 18, 19):
+        m.set_conv_tile(tile)
+        lows[tile] = m.lowres_logits(x.to(DEV)).cpu()
+        torch.cuda.synchronize()
+        worst = ("", 0.0)
+        for name, want in ref.items():
+            got = lows[tile].numpy() if name == "classifier.4" else m.read_activation(name, want.numel())
+            want = want.numpy()
+            scale = float(np.abs(want).max())
+            err = float(np.abs(got - want).max()) / scale
+            worst = max(worst, (name, err), key=lambda t: t[1])
+            assert err <= LAYER_RTOL_FP32, f"{name}: rel err {err} (tile {tile}, shape {shape})"
+        print("shape", shape, "tile", tile, "worst layer rel err", worst)
+    assert torch.equal(lows[-1], lows[18]) and torch.equal(lows[-1], lows[19])
+    # the planned tiles of the eligible layers are the row kernel's, of every other layer the generic ones
+    m.set_conv_tile(-1)
+    m.lowres_logits(x.to(DEV))
+    planned = m.plan_tiles()
+    assert sum(t >= 18 for t in planned) == 10 and len(planned) == 54          # 6 + 3 conv2 + classifier.0
+    m.set_keep_activations(False)
+
+
 @pytest.mark.parametrize("name", ["c128", "b2_256", "odd_h", "h520", "full1024"])
 def test_fp32_end_to_end_vs_oracle_and_goldens(oracle_model, gpu_fp32, name):
     g = load_golden(name)
