@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libnbc_hip.so")
-SOURCES = ["nbc_net.cpp", "conv_igemm_dma.hip", "conv3x3_rows.hip", "conv1x1_stream.hip", "pointwise.hip", "small_zones.hip", "nbc_api.hip"]
+SOURCES = ["nbc_net.cpp", "conv_igemm_dma.hip", "conv3x3_rows.hip", "pointwise.hip", "small_zones.hip", "nbc_api.hip"]
 ARCH = "gfx950"
 
 

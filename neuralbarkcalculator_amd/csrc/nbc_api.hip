@@ -40,7 +40,6 @@ struct Op {
   double flops, bytes;
   int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
   bool rows;           // OP_CONV: runs on the row-resident 3x3 kernel (tiles 18 / 19 only; conv_rows_eligible)
-  bool stream;         // OP_CONV: the streaming 1x1 kernel (tile 20) may take it (conv_stream_eligible)
 };
 
 struct Plan {
@@ -152,8 +151,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
     o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
     o.rows = conv_rows_eligible(c->precision, u.k, u.stride, u.pad, u.dil, inH, inW, Ho, Wo, inC, u.cout, res_buf >= 0);
-    o.stream = conv_stream_eligible(c->precision, u.k, u.pad, inC, u.cout, N * Ho * Wo, L.convs[ui].ksteps, L.convs[ui].stem);
-    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision, o.rows, o.stream);
+    o.tile = choose_conv_tile(N * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision, o.rows);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
     o.bytes = ((double)N * inH * inW * u.cin + (double)u.cout * u.cin * u.k * u.k + M * u.cout +
@@ -592,7 +590,7 @@ int nbc_forward(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W,
         break;
       case OP_CONV: {
         int tile = c->conv_tile;
-        if (!conv_tile_ok(prec, tile, o.Co, o.rows, o.stream)) tile = o.tile;   // no override, or it does not fit (a generic tile on a
+        if (!conv_tile_ok(prec, tile, o.Co, o.rows)) tile = o.tile;   // no override, or it does not fit (a generic tile on a
                                                                       // layer of the row-resident kernel, or the reverse): planned tile
         rc = launch_conv_op(c, o, N, tile, s, &e);
         if (rc != NBC_OK) return rc;
@@ -685,7 +683,7 @@ int nbc_autotune(nbc_ctx* c, const void* x_dev, int x_dtype, int N, int H, int W
     float best_ms = 1e30f;
     int best = o.tile;
     for (int tile = 0; tile < CONV_TILE_COUNT; ++tile) {
-      if (!conv_tile_ok(c->precision, tile, o.Co, o.rows, o.stream)) continue;
+      if (!conv_tile_ok(c->precision, tile, o.Co, o.rows)) continue;
       hipError_t e = hipSuccess;
       rc = launch_conv_op(c, o, NB, tile, s, &e);                         // warm-up (and attribute set-up)
       if (rc != NBC_OK || e != hipSuccess) continue;
@@ -720,7 +718,7 @@ int nbc_get_plan_tiles(nbc_ctx* c, int32_t* tiles, int capacity) {
 
 int nbc_default_conv_tile(int M, int Cout, int K, int precision) {
   if (M < 1 || Cout < 1 || K < 1) return -1;
-  return choose_conv_tile(M, Cout, K, precision, false, false);
+  return choose_conv_tile(M, Cout, K, precision, false);
 }
 
 int nbc_set_plan_tiles(nbc_ctx* c, const int32_t* tiles, int n) {
@@ -733,7 +731,7 @@ int nbc_set_plan_tiles(nbc_ctx* c, const int32_t* tiles, int n) {
   for (const Op& o : c->plan.ops) {
     if (o.kind != OP_CONV) continue;
     const int t = tiles[k++];
-    if (!conv_tile_ok(c->precision, t, o.Co, o.rows, o.stream))
+    if (!conv_tile_ok(c->precision, t, o.Co, o.rows))
       return set_error(NBC_ERR_INVALID, "nbc_set_plan_tiles: tile " + std::to_string(t) + " does not fit " + o.name);
   }
   k = 0;

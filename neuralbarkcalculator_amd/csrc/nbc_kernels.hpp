@@ -34,9 +34,7 @@ struct ConvArgs {
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16),
 // 2 = f16x2 (two f16 pieces per f32 value, three v_mfma_f32_16x16x32_f16 per product: split16.hpp)
 // LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
-constexpr int CONV_TILE_COUNT = 21;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19 = the row-resident 3x3 kernel,
-                                      // 20 = the streaming 1x1 kernel (conv1x1_stream.hip)
-constexpr int CONV_TILE_STREAM = 20;
+constexpr int CONV_TILE_COUNT = 20;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19 = the row-resident 3x3 kernel
 constexpr int CONV_TILE_ROWS_FIRST = 18;   // (conv3x3_rows.hip: one / two image rows x 128 channels)
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
@@ -44,14 +42,9 @@ int conv_tile_cols(int tile);
 // channels, no identity): a property of the layer and its shape that fixes its K order, so such a convolution runs on
 // tiles 18 / 19 ONLY and every other one on tiles 0 .. 17 only (conv3x3_rows.hip).
 bool conv_rows_eligible(int precision, int k, int stride, int pad, int dil, int Hi, int Wi, int Ho, int Wo, int Ci, int Co, bool has_res);
-// Whether the streaming 1x1 kernel (tile 20, f16x2: one persistent workgroup per CU, the epilogue of a tile under the K loop
-// of the next) takes a convolution: 1x1, no padding, 512 tiles of 128 x 128 or more.  Same K order as the generic tiles.
-bool conv_stream_eligible(int precision, int k, int pad, int Ci, int Co, int M, int ksteps, bool stem);
-// the tile exists for the precision and the kind of convolution and divides Co (stream: conv_stream_eligible)
-bool conv_tile_ok(int precision, int tile, int Co, bool rows, bool stream);
-// K = Cin*kh*kw; the default tile of a layer (cost model); rows: conv_rows_eligible; stream: conv_stream_eligible
-int choose_conv_tile(int M, int Co, int K, int precision, bool rows, bool stream);
-hipError_t launch_conv1x1_stream(const ConvArgs& a, hipStream_t s);
+bool conv_tile_ok(int precision, int tile, int Co, bool rows);   // the tile exists for the precision and the kind of convolution and divides Co
+// K = Cin*kh*kw; the default tile of a layer (cost model); rows: conv_rows_eligible
+int choose_conv_tile(int M, int Co, int K, int precision, bool rows);
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
 hipError_t launch_conv3x3_rows(const ConvArgs& a, int rows_tile, hipStream_t s);   // rows_tile: tile id - CONV_TILE_ROWS_FIRST
 

@@ -133,31 +133,6 @@ def test_every_conv_unit_with_rescaled_activations(built_lib, sd_np):
         assert not model.nonfinite_seen()
 
 
-@pytest.mark.parametrize("shape", [(1, 1024, 1024), (2, 520, 1024), (1, 1000, 1016), (8, 264, 1024)])
-def test_streaming_1x1_kernel_equals_the_generic_tiles(built_lib, sd_np, shape):
-    """Tile 20 (csrc/conv1x1_stream.hip, "f16x2": one persistent workgroup per CU whose epilogue waves drain tile i while the
-    MFMA waves run the K loop of tile i+1) keeps the generic kernel's K order and epilogue arithmetic: forced on every
-    convolution it is eligible for (1x1, 512 tiles of 128 x 128 or more: conv3 + identity, the downsample convolutions with
-    stride 1 and 2, layer4's conv1), the logits are the default plan's bit for bit -- on the full frame, a batch of trimmed
-    scans, a width whose maps end inside a tile (M not a multiple of 128) and a batch of eight."""
-    n, h, w = shape
-    x = frames(range(40, 40 + n), h, w).to(DEV)
-    m = FCNResNet50("f16x2").load_state_dict(sd_np).to(DEV)
-    m.set_conv_tile(-1)
-    ref = m.lowres_logits(x).cpu()
-    planned = m.plan_tiles()
-    m.set_conv_tile(20)
-    got = m.lowres_logits(x).cpu()
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(ref).all())
-    assert torch.equal(ref, got), float((ref - got).abs().max())
-    lab_a, cnt_a = m.predict_labels(x, labels_dtype=torch.uint8)
-    m.set_conv_tile(-1)
-    lab_b, cnt_b = m.predict_labels(x, labels_dtype=torch.uint8)
-    assert torch.equal(lab_a, lab_b) and torch.equal(cnt_a, cnt_b)
-    print("shape", shape, "default plan:", planned)
-
-
 @pytest.mark.parametrize("shape", [(1, 72, 1024), (2, 40, 1024), (1, 8, 1024), (3, 24, 1024)])
 def test_row_resident_3x3_kernel_layer_by_layer(oracle_model, built_lib, sd_np, shape):
     """The 3x3 layers of a 1024-pixel-wide image (128-pixel-wide maps from layer2 on) with 256 output channels or more --
