@@ -39,7 +39,7 @@ struct Op {
   std::string name;
   double flops, bytes;
   int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
-  bool rows;           // OP_CONV: runs on the row-resident 3x3 kernel (tiles 18 / 19 only; conv_rows_eligible)
+  int rows;            // OP_CONV: conv_rows_kind: 0 generic tiles, 1 / 2 the row-resident 3x3 kernels (tiles 18, 19 / 20 only)
 };
 
 struct Plan {
@@ -150,7 +150,7 @@ int build_plan(nbc_ctx* c, int N, int H, int W) {
     o.kind = OP_CONV; o.unit = ui; o.in_buf = in_buf; o.res_buf = res_buf;
     o.Hi = inH; o.Wi = inW; o.Ci = inC; o.Ho = Ho; o.Wo = Wo; o.Co = u.cout; o.name = u.name;
     o.out_buf = acquire((size_t)N * Ho * Wo * u.cout * eb);
-    o.rows = conv_rows_eligible(c->precision, u.k, u.stride, u.pad, u.dil, inH, inW, Ho, Wo, inC, u.cout, res_buf >= 0);
+    o.rows = conv_rows_kind(c->precision, u.k, u.stride, u.pad, u.dil, inH, inW, Ho, Wo, inC, u.cout, res_buf >= 0);
     o.tile = choose_conv_tile(N * Ho * Wo, u.cout, u.cin * u.k * u.k, c->precision, o.rows);
     const double M = (double)N * Ho * Wo;
     o.flops = 2.0 * M * u.cout * u.cin * u.k * u.k;
@@ -718,7 +718,7 @@ int nbc_get_plan_tiles(nbc_ctx* c, int32_t* tiles, int capacity) {
 
 int nbc_default_conv_tile(int M, int Cout, int K, int precision) {
   if (M < 1 || Cout < 1 || K < 1) return -1;
-  return choose_conv_tile(M, Cout, K, precision, false);
+  return choose_conv_tile(M, Cout, K, precision, 0);
 }
 
 int nbc_set_plan_tiles(nbc_ctx* c, const int32_t* tiles, int n) {

@@ -34,17 +34,18 @@ struct ConvArgs {
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16),
 // 2 = f16x2 (two f16 pieces per f32 value, three v_mfma_f32_16x16x32_f16 per product: split16.hpp)
 // LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
-constexpr int CONV_TILE_COUNT = 20;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19 = the row-resident 3x3 kernel
+constexpr int CONV_TILE_COUNT = 21;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19, 20 = the row-resident 3x3 kernels
 constexpr int CONV_TILE_ROWS_FIRST = 18;   // (conv3x3_rows.hip: one / two image rows x 128 channels)
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
-// Whether a convolution runs on the row-resident 3x3 kernel (f16x2; 3x3, stride 1, 128-pixel-wide maps, >= 256 output
-// channels, no identity): a property of the layer and its shape that fixes its K order, so such a convolution runs on
-// tiles 18 / 19 ONLY and every other one on tiles 0 .. 17 only (conv3x3_rows.hip).
-bool conv_rows_eligible(int precision, int k, int stride, int pad, int dil, int Hi, int Wi, int Ho, int Wo, int Ci, int Co, bool has_res);
-bool conv_tile_ok(int precision, int tile, int Co, bool rows);   // the tile exists for the precision and the kind of convolution and divides Co
-// K = Cin*kh*kw; the default tile of a layer (cost model); rows: conv_rows_eligible
-int choose_conv_tile(int M, int Co, int K, int precision, bool rows);
+// Whether a convolution runs on the row-resident 3x3 kernels (conv3x3_rows.hip; f16x2, 3x3, stride 1, no identity): 0 no;
+// 1: 128-pixel-wide maps, >= 256 output channels: tiles 18 / 19 ONLY; 2: 128-pixel-wide maps, 64 / 128 output channels:
+// tile 20 ONLY.  A property of the layer and its shape that fixes its K order; every other convolution runs on
+// tiles 0 .. 17 only.
+int conv_rows_kind(int precision, int k, int stride, int pad, int dil, int Hi, int Wi, int Ho, int Wo, int Ci, int Co, bool has_res);
+bool conv_tile_ok(int precision, int tile, int Co, int rows_kind);   // the tile exists for the precision and the kind of convolution and divides Co
+// K = Cin*kh*kw; the default tile of a layer (cost model); rows_kind: conv_rows_kind
+int choose_conv_tile(int M, int Co, int K, int precision, int rows_kind);
 hipError_t launch_conv_dma(const ConvArgs& a, int precision, int tile, hipStream_t s);
 hipError_t launch_conv3x3_rows(const ConvArgs& a, int rows_tile, hipStream_t s);   // rows_tile: tile id - CONV_TILE_ROWS_FIRST
 
