@@ -1127,14 +1127,13 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
   }
 }
 
-//   18  128x128   row-step kernel (conv3x3_rows.hip: ONE image row x 128 channels, eight 64x32 MFMA waves + four loader waves,
-//                                one barrier per (channel block, kh))
-//   19  256x128   rows kernel    (TWO image rows x 128 channels, eight 64x64 waves, one barrier per K-step): the 3x3 layers of 128-pixel-wide maps
-//                                with 256 output channels or more run on 18 / 19 and on nothing else (conv_rows_kind 1)
-//   20  128x64    row-step kernel (a 128-pixel row segment x 64 channels, one barrier per (channel block, kh)): the 3x3 layers with
-//                                64 / 128 output channels on 128-pixel-wide maps (layer2.1-3 conv2; conv_rows_kind 2)
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128, 128, 256, 128};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128, 128, 128, 64};
+//   18  128x128   row-step kernel (conv3x3_rows.hip: ONE image row x 128 channels, eight 64x32 MFMA waves + four loader waves, the
+//                                row in LDS for its three taps, one barrier per (channel block, kh)): the 3x3 layers of
+//                                128-pixel-wide maps with 256 output channels or more run on it and on nothing else
+//   19  128x64    row-step kernel (one image row x 64 channels, four MFMA + four loader waves): likewise those with 64 / 128
+//                                output channels (layer2.1-3 conv2; conv_rows_kind)
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128, 128, 64};
 
 }  // namespace
 
@@ -1144,8 +1143,8 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 // Whether tile id `tile` exists for this precision and divides the layer's output channels.
 bool conv_tile_ok(int precision, int tile, int Co, int rows_kind) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
-  // the row-resident 3x3 kernels' tiles and the generic ones: never mixed (kind 1: 18, 19; kind 2: 20; kind 0: 0 .. 17)
-  const int tile_kind = tile < CONV_TILE_ROWS_FIRST ? 0 : (tile < CONV_TILE_ROWS_FIRST + 2 ? 1 : 2);
+  // the row-resident 3x3 kernel's tiles and the generic ones: never mixed (kind 1: 18; kind 2: 19; kind 0: 0 .. 17)
+  const int tile_kind = tile < CONV_TILE_ROWS_FIRST ? 0 : tile - CONV_TILE_ROWS_FIRST + 1;
   if (rows_kind != tile_kind) return false;
   if (rows_kind != 0) return precision == 2 && Co % kTileCols[tile] == 0;
   if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
@@ -1181,25 +1180,25 @@ struct TileModel {
 constexpr TileModel kTileModel[3] = {
     // f32: 157.3 TF / 256 CUs
     {157.3e6 / 256.0,
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
     // bf16: against the 1 400 TF/s the chip sustains on this kernel (power-limited), / 256 CUs
     {1400.0e6 / 256.0,
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
-     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0},
-     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
     // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs
     {839.0e6 / 256.0,
-     {0.421, 0.52, 0.5, 0.5, 0.5, 0.535, 0.42, 0.476, 0.42, 0.42, 0.455, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.501, 0.50, 0.60, 0.45},
-     {0.38, 0.36, 0.5, 0.5, 0.5, 0.535, 0.42, 0.383, 0.36, 0.42, 0.392, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.36, 0.50, 0.60, 0.45},
-     {3, 3, 3, 3, 3, 3.45, 3.007, 3, 2.746, 3, 2.868, 3, 3, 2.518, 3.874, 3, 3, 3.321, 4.0, 4.0, 3.0},
-     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.309, 0.31, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.195, 0.2, 0.15, 0.3},
-     {2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1}}};
+     {0.421, 0.52, 0.5, 0.5, 0.5, 0.535, 0.42, 0.476, 0.42, 0.42, 0.455, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.501, 0.50, 0.45},
+     {0.38, 0.36, 0.5, 0.5, 0.5, 0.535, 0.42, 0.383, 0.36, 0.42, 0.392, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.36, 0.50, 0.45},
+     {3, 3, 3, 3, 3, 3.45, 3.007, 3, 2.746, 3, 2.868, 3, 3, 2.518, 3.874, 3, 3, 3.321, 4.0, 3.0},
+     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.309, 0.31, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.195, 0.2, 0.3},
+     {2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1}}};
 }  // namespace
 
 int choose_conv_tile(int M, int Co, int K, int precision, int rows_kind) {

@@ -39,7 +39,7 @@ struct Op {
   std::string name;
   double flops, bytes;
   int tile;            // OP_CONV: tile id of the LDS-DMA kernel (default choice or autotuned)
-  int rows;            // OP_CONV: conv_rows_kind: 0 generic tiles, 1 / 2 the row-resident 3x3 kernels (tiles 18, 19 / 20 only)
+  int rows;            // OP_CONV: conv_rows_kind: 0 generic tiles, 1 / 2 the row-resident 3x3 kernel (tile 18 / 19 only)
 };
 
 struct Plan {

@@ -34,13 +34,12 @@ struct ConvArgs {
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16),
 // 2 = f16x2 (two f16 pieces per f32 value, three v_mfma_f32_16x16x32_f16 per product: split16.hpp)
 // LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
-constexpr int CONV_TILE_COUNT = 21;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19, 20 = the row-resident 3x3 kernels
-constexpr int CONV_TILE_ROWS_FIRST = 18;   // (conv3x3_rows.hip: one / two image rows x 128 channels)
+constexpr int CONV_TILE_COUNT = 20;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19 = the row-resident 3x3 kernel
+constexpr int CONV_TILE_ROWS_FIRST = 18;   // (conv3x3_rows.hip: one image row x 128 / 64 channels)
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 // Whether a convolution runs on the row-resident 3x3 kernels (conv3x3_rows.hip; f16x2, 3x3, stride 1, no identity): 0 no;
-// 1: 128-pixel-wide maps, >= 256 output channels: tiles 18 / 19 ONLY; 2: 128-pixel-wide maps, 64 / 128 output channels:
-// tile 20 ONLY.  A property of the layer and its shape that fixes its K order; every other convolution runs on
+// 1: 128-pixel-wide maps, >= 256 output channels: tile 18 ONLY; 2: 128-pixel-wide maps, 64 / 128 output channels: tile 19 ONLY.  A property of the layer and its shape that fixes its K order; every other convolution runs on
 // tiles 0 .. 17 only.
 int conv_rows_kind(int precision, int k, int stride, int pad, int dil, int Hi, int Wi, int Ho, int Wo, int Ci, int Co, bool has_res);
 bool conv_tile_ok(int precision, int tile, int Co, int rows_kind);   // the tile exists for the precision and the kind of convolution and divides Co
