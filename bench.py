@@ -346,7 +346,8 @@ def main():
         bound_s = sum(max(r["flops"] / (peak * 1e12), r["bytes"] / HBM_MEASURED) for r in records)
         out = {
             "bound": "mfma",
-            "kernel": "conv_dma_kernel<%s> (LDS-DMA implicit GEMM; every convolution with Cout %% 128 == 0, stem excluded)" % prec,
+            "kernel": "conv_dma_kernel<%s>%s (LDS-DMA implicit GEMM; every convolution with Cout %% 128 == 0, stem excluded)"
+                      % (prec, " + conv3x3_rowstep_kernel (its 3x3 layers of 128-pixel-wide maps: rows resident in LDS, one barrier per row-step)" if prec == "f16x2" else ""),
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
             "measured_on": "second region of K steps, one stream, a HIP event between launches on the forward's stream, "
                            "latency-tuned tiles; RAW event durations (each includes its event packet, nothing subtracted)",

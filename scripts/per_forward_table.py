@@ -139,7 +139,8 @@ def main():
             d["mfma_util"] = round(sum(r["mfma_busy_cycles"] for r in rows) / (sum(r["shader_cycles"] for r in rows) * SIMDS), 4)
         return d
 
-    conv = [r for r in table if "conv_dma_kernel" in r["kernel"]]
+    # the convolution kernels: the generic LDS-DMA kernel and (f16x2) the row-resident 3x3 kernel
+    conv = [r for r in table if "conv_dma_kernel" in r["kernel"] or "conv3x3_rowstep_kernel" in r["kernel"]]
     dom = [r for r in conv if r["cout"] % 128 == 0 and r["op"] != "backbone.conv1"]
     stages = {}
     for r in table:
