@@ -293,6 +293,14 @@ int nbc_nonfinite_peek_async(nbc_ctx* ctx, uint32_t* host_dst, void* hip_stream)
 /* Copy the activation written by conv unit `name` during the last forward to `dst_host` as
  * float32 NCHW.  `capacity` is in elements.  Only valid when keep-activations is on. */
 int nbc_set_keep_activations(nbc_ctx* ctx, int on);
+/* The calibration guard of NBC_PREC_F16X2 (any precision answers): after a forward with keep-activations on, the largest
+ * finite |value| of every conv unit's output tensor AS STORED on the device (with the power of two nbc_pack_weights gave it),
+ * one float per conv unit in nbc_conv_info order (0 for classifier.4, whose output is the logits); returns their number
+ * (nbc_num_convs()) or a negative error.  nbc_pack_weights places a tensor by its BatchNorm's promise; this is what the
+ * data did.  A tensor that peaks below 2^-8 has most of its values under f16x2's 2^-12 floor (absolute error 2^-36), one
+ * beyond 2^14 is a factor four from f16's range: a caller that sees either on a frame of its data runs NBC_PREC_FP32
+ * (the folder driver checks its first image: neuralbarkcalculator_amd/predict.py).  Synchronises the device. */
+int nbc_activation_peaks(nbc_ctx* ctx, float* peaks_host, int capacity);
 int nbc_read_activation(nbc_ctx* ctx, const char* name, float* dst_host, size_t capacity,
                         int64_t shape[4]);
 /* When on, every launch of the next forwards is bracketed by HIP events on the forward's stream

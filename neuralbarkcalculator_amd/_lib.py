@@ -80,6 +80,7 @@ SIGNATURES = {
     "nbc_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "nbc_set_conv_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "nbc_set_keep_activations": (C.c_int, [C.c_void_p, C.c_int]),
+    "nbc_activation_peaks": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "nbc_read_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
                                       C.POINTER(C.c_int64 * 4)]),
     "nbc_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),

@@ -817,6 +817,29 @@ int nbc_get_op_record(nbc_ctx* c, int index, nbc_op_record* out) {
   return NBC_OK;
 }
 
+int nbc_activation_peaks(nbc_ctx* c, float* peaks_host, int capacity) {
+  if (!c || !peaks_host) return set_error(NBC_ERR_INVALID, "nbc_activation_peaks: null argument");
+  if (!c->plan.keep) return set_error(NBC_ERR_STATE, "nbc_activation_peaks: keep-activations is off (nbc_set_keep_activations, then a forward)");
+  const int nunits = (int)conv_units().size();
+  if (capacity < nunits) return set_error(NBC_ERR_INVALID, "nbc_activation_peaks: need room for nbc_num_convs() values");
+  NBC_HIP(hipSetDevice(c->device));
+  unsigned* dev = nullptr;
+  NBC_HIP(hipMalloc((void**)&dev, sizeof(unsigned) * nunits));
+  hipError_t e = hipMemset(dev, 0, sizeof(unsigned) * nunits);
+  const int N = c->plan.N;
+  for (const Op& o : c->plan.ops) {
+    if (e != hipSuccess) break;
+    if (o.kind != OP_CONV || o.out_buf < 0) continue;
+    e = launch_absmax(c->bufs[o.out_buf], (size_t)N * o.Ho * o.Wo * o.Co, o.Co, c->precision, dev + o.unit, nullptr);
+  }
+  std::vector<unsigned> bits(nunits, 0u);
+  if (e == hipSuccess) e = hipMemcpy(bits.data(), dev, sizeof(unsigned) * nunits, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return set_error(NBC_ERR_HIP, std::string("nbc_activation_peaks: ") + hipGetErrorString(e));
+  for (int u = 0; u < nunits; ++u) std::memcpy(&peaks_host[u], &bits[u], 4);
+  return nunits;
+}
+
 int nbc_read_activation(nbc_ctx* c, const char* name, float* dst_host, size_t capacity, int64_t shape[4]) {
   if (!c || !name || !dst_host) return set_error(NBC_ERR_INVALID, "nbc_read_activation: null argument");
   if (!c->plan.keep) return set_error(NBC_ERR_STATE, "nbc_read_activation: keep-activations is off");

@@ -81,4 +81,7 @@ hipError_t launch_resize_cubic_u8(const uint8_t* src, int H, int W, float* dst, 
 hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W, int C, int precision,
                                    hipStream_t s);
 
+// Largest finite |value| of `elems` stored activation elements (C channels per pixel) as float bits, atomicMax-ed into *out.
+hipError_t launch_absmax(const void* x, size_t elems, int C, int precision, unsigned* out, hipStream_t s);
+
 }  // namespace nbc

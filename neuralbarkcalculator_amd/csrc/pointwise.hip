@@ -457,6 +457,28 @@ __global__ void nhwc_to_nchw_kernel(const void* __restrict__ x, float* __restric
   }
 }
 
+// Largest finite |value| of an activation tensor as it is STORED (f16x2: pieces joined; the calibration guard of
+// nbc_activation_peaks): one wave-reduced atomicMax on the float's bit pattern (non-negative floats order like integers).
+template <int PREC>
+__global__ void absmax_kernel(const void* __restrict__ x, size_t elems, int C, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < elems; i += (size_t)gridDim.x * blockDim.x) {
+    float v;
+    if constexpr (PREC == 0) v = static_cast<const float*>(x)[i];
+    else if constexpr (PREC == 2) {
+      const size_t pix = i / C;
+      const int c = (int)(i - pix * C);
+      const _Float16* hp = static_cast<const _Float16*>(x) + pix * (size_t)C * 2 + (c >> 5) * 64 + (c & 31);
+      v = join16(hp[0], hp[32]);
+    } else v = bf16_bits_to_f32(static_cast<const unsigned short*>(x)[i]);
+    v = __builtin_fabsf(v);
+    if (v < __builtin_inff() && v > m) m = v;          // NaN and infinity do not count (the non-finite flag reports those)
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
 // ---- preprocessor (next-row N4): models.py:191-198, skimage.transform.resize(order=3, mode='reflect',
 // anti_aliasing=False) of the ToTensor'd image, as scikit-image 0.18.3's compiled _warp_fast evaluates it for a
 // float32 image (restated and pinned value for value in neuralbarkcalculator_amd/predict.py,
@@ -671,6 +693,14 @@ hipError_t launch_nhwc_to_nchw_f32(const void* x, float* y, int N, int H, int W,
   if (precision == 0) hipLaunchKernelGGL(nhwc_to_nchw_kernel<0>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
   else if (precision == 2) hipLaunchKernelGGL(nhwc_to_nchw_kernel<2>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
   else hipLaunchKernelGGL(nhwc_to_nchw_kernel<1>, dim3(g), dim3(256), 0, s, x, y, N, H * W, C);
+  return hipGetLastError();
+}
+
+hipError_t launch_absmax(const void* x, size_t elems, int C, int precision, unsigned* out, hipStream_t s) {
+  const int g = grid_for(elems, 256);
+  if (precision == 0) hipLaunchKernelGGL(absmax_kernel<0>, dim3(g), dim3(256), 0, s, x, elems, C, out);
+  else if (precision == 2) hipLaunchKernelGGL(absmax_kernel<2>, dim3(g), dim3(256), 0, s, x, elems, C, out);
+  else hipLaunchKernelGGL(absmax_kernel<1>, dim3(g), dim3(256), 0, s, x, elems, C, out);
   return hipGetLastError();
 }
 

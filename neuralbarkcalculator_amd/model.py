@@ -18,7 +18,7 @@ from typing import Mapping, Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, topology
 from .topology import NUM_CLASSES, out_hw
 
 _PRECISIONS = {"fp32": _lib.PREC_FP32, "f32": _lib.PREC_FP32, "float32": _lib.PREC_FP32,
@@ -325,6 +325,32 @@ class FCNResNet50:
         e = C.c_int32(0)
         _lib.check(self._lib.nbc_activation_exponent(self._require_ctx(), name.encode(), C.byref(e)), "nbc_activation_exponent")
         return int(e.value)
+
+    def activation_peaks(self, x: torch.Tensor) -> dict:
+        """One forward of ``x`` with every activation kept, then the largest finite |value| of each conv unit's output AS
+        STORED on the device (nbc_activation_peaks): ``{conv unit name: peak}``, classifier.4 left out.  The calibration
+        guard of "f16x2": a tensor that peaks below 2^-8 (or beyond 2^14) on real data belongs in "fp32"
+        (``f16x2_range_ok``)."""
+        n, h, w = self._check_input(x)
+        self.set_keep_activations(True)
+        try:
+            self._forward(x, n, h, w, lowres=torch.empty((n, NUM_CLASSES) + out_hw(h, w), dtype=torch.float32, device=self.device))
+            torch.cuda.synchronize(self.device)
+            k = int(self._lib.nbc_num_convs())
+            buf = (C.c_float * k)()
+            rc = self._lib.nbc_activation_peaks(self._require_ctx(), buf, k)
+            if rc < 0:
+                _lib.check(rc, "nbc_activation_peaks")
+        finally:
+            self.set_keep_activations(False)
+        names = [u.name for u in topology.conv_units()]
+        return {names[i]: float(buf[i]) for i in range(k) if names[i] != "classifier.4"}
+
+    @staticmethod
+    def f16x2_range_ok(peaks: dict, low: float = 2.0 ** -8, high: float = 2.0 ** 14):
+        """(ok, offenders): whether every stored tensor of ``activation_peaks`` lies where the f16 pieces hold f32 grade."""
+        bad = {k: v for k, v in peaks.items() if not (low <= v <= high)}
+        return (not bad), bad
 
     def nonfinite_seen(self, reset: bool = True) -> bool:
         """True when a forward since the last reset produced a NaN / infinite logit (nbc_nonfinite_seen; synchronises).

@@ -412,7 +412,7 @@ def plan_items(root: str) -> List[dict]:
 
 def predict_folder(root: str, model_path: str = "./best_model.pt", precision: str = "fp32",
                    exclude_nodes: bool = False, small_zones: bool = True, device_index: int = None,
-                   batch: int = None, window: int = 64, target_size: int = 1024, autotune: bool = False,
+                   batch: int = None, window: int = 64, target_size: int = 1024, autotune: bool = False, calibrate: bool = True,
                    streams: int = None) -> dict:
     """predict.py:51-58 + models.py:230-364 with the model call on the MI355X path.
 
@@ -427,7 +427,10 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
     images/s at 528 rows, 146 -> 168 at 720, 118 -> 119 at 1024; default 4).  Every shape runs on the library's default per-layer tiles (a cost model that
     lands within 0.1-0.5 % of the measured best in f32); ``autotune=True`` measures them once per distinct
     full-batch shape instead, which costs 0.5-0.9 s per shape and pays only for many thousands of images of one
-    shape.  Returns timing / count statistics of this rank."""
+    shape.  In "f16x2" mode ``calibrate`` (default) runs the first image once with every activation kept and leaves with
+    ``NonFiniteLogits`` -- before any batch -- when a stored tensor lies outside the range the f16 pieces hold at f32 grade
+    (``FCNResNet50.activation_peaks``: the silent counterpart of the non-finite word, which still rides back with every batch).
+    Returns timing / count statistics of this rank."""
     import time
     import torch
     from collections import defaultdict, deque
@@ -568,6 +571,32 @@ def predict_folder(root: str, model_path: str = "./best_model.pt", precision: st
         cnts = cnt_host[:n].numpy().copy()
         for j, (k, gi) in enumerate(members):
             done.append(pool.submit(finish, k, gi, labs[j], int(cnts[j, 1]), int(cnts[j, 2])))
+
+    # f16x2, calibration guard: nbc_pack_weights places every tensor by its BatchNorm's promise (|beta| + 3 |gamma|); whether the
+    # DATA keeps that promise shows on the first image: rank 0 runs it once with every activation kept and looks at each
+    # stored tensor's largest value.  One below 2^-8 sits mostly under the f16 pieces' 2^-12 floor -- finite logits, nothing
+    # for the non-finite flag to see --, one beyond 2^14 is a factor four from f16's range: either way the folder belongs on
+    # the f32 MFMA, and every rank leaves here alike (one scalar broadcast), before any batch has run.
+    if check_flag and calibrate:
+        verdict = torch.zeros(1, dtype=torch.int32)
+        offenders = {}
+        if rank == 0 and len(mine) > 0:
+            first = prepare(mine[0])                     # (decoded once more inside the loop: one image's host work)
+            peaks = models[0].activation_peaks(torch.from_numpy(np.ascontiguousarray(first[None])).to(dev))
+            ok, offenders = FCNResNet50.f16x2_range_ok(peaks)
+            verdict[0] = 0 if ok else 1
+        if dist is not None:
+            vd = verdict.to(dev) if dist.get_backend() == "nccl" else verdict
+            dist.broadcast(vd, src=0)
+            verdict = vd.cpu()
+        if int(verdict[0]) != 0:
+            pool.shutdown(wait=True, cancel_futures=True)
+            worst = ", ".join("%s %.3g" % kv for kv in sorted(offenders.items(), key=lambda kv: kv[1])[:4])
+            err = NonFiniteLogits("calibration on the first image: an activation tensor lies outside the range the f16 pieces hold "
+                                  "at f32 grade (stored peak below 2^-8 or beyond 2^14%s): f16x2 would lose bits silently on this "
+                                  "checkpoint; rerun with --precision fp32" % ((": " + worst) if worst else ""))
+            err.batches_run, err.images_this_rank = 0, len(mine)
+            raise err
 
     # the GPU loop runs in this thread next to up to 32 busy pool threads: a short switch interval keeps it
     # from waiting 5 ms for the interpreter lock at every step (restored below)

@@ -314,10 +314,10 @@ def test_cli_falls_back_to_fp32_when_f16x2_overflows(tmp_path, sd_np, built_lib)
     with pytest.raises(drv.NonFiniteLogits):
         drv.predict_folder(root_call, ckpt2, precision="f16x2", device_index=0)
     # the invalid run leaves no label PNG behind (a crash before the fp32 rerun must not leave invalid masks without a
-    # CSV); what the preprocessor wrote does not depend on the arithmetic and stays
+    # CSV).  (Since round 5 the calibration guard stops this checkpoint on the FIRST image, before any batch: what the
+    # preprocessor wrote by then does not depend on the arithmetic and stays; the fp32 run writes the rest.)
     for wood, name in (("sapin", "a.png"), ("epinette_gelee", "c.png")):
         assert not os.path.exists(os.path.join(root_call, "results", "outputs", wood, name))
-        assert os.path.exists(os.path.join(root_call, "processed", "samples", wood, name))
     assert not os.path.exists(os.path.join(root_call, "results", "final_stats.csv"))
     drv.predict_folder(root_call, ckpt2, precision="fp32", device_index=0)
     assert open(os.path.join(root_cli, "results", "final_stats.csv")).read() == open(os.path.join(root_call, "results", "final_stats.csv")).read()
@@ -336,8 +336,10 @@ def test_f16x2_overflow_abandons_the_folder_at_the_first_batches(tmp_path, sd_np
     root = str(tmp_path / "many")
     ckpt, _ = _make_folder(root, big, layout)
     with pytest.raises(drv.NonFiniteLogits) as e:
-        drv.predict_folder(root, ckpt, precision="f16x2", device_index=0, batch=1, streams=2, window=4)
-    assert e.value.images_this_rank == 24 and e.value.batches_run <= 8, e.value.batches_run    # two windows at most
+        # (calibrate=False: the calibration guard would stop this checkpoint on the first image, before any batch; the word that
+        # rides back with every batch is the second line, for an image later in the folder)
+        drv.predict_folder(root, ckpt, precision="f16x2", device_index=0, batch=1, streams=2, window=4, calibrate=False)
+    assert e.value.images_this_rank == 24 and 1 <= e.value.batches_run <= 8, e.value.batches_run    # two windows at most
     out = os.path.join(root, "results", "outputs", "sapin")
     assert not os.path.isdir(out) or os.listdir(out) == []
     st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0, batch=1, streams=2, window=4)
@@ -359,3 +361,45 @@ def test_f16x2_refuses_weights_the_packer_flags_before_any_forward(tmp_path, sd_
     assert e.value.batches_run == 0 and "NBC_PACK flags 1" in str(e.value)
     st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0)
     assert st["images_total"] == 1
+
+
+def _stats_do_not_describe_the_data(sd):
+    """A checkpoint whose BatchNorm PROMISES an ordinary tensor (gamma of order one) and whose data does not keep the promise:
+    layer2.1's conv1 at 2^-22 of its usual size under a BatchNorm with zero mean and bias and unit variance -- the tensor behind
+    it peaks around 2^-20.  nbc_pack_weights, which reads the BatchNorm, gives it no power of two; the calibration guard,
+    which reads the data, sees it."""
+    out = dict(sd)
+    out["backbone.layer2.1.conv1.weight"] = sd["backbone.layer2.1.conv1.weight"] * np.float32(2.0 ** -22)
+    for k, v in (("running_mean", 0.0), ("bias", 0.0), ("running_var", 1.0)):
+        out["backbone.layer2.1.bn1." + k] = np.full_like(sd["backbone.layer2.1.bn1." + k], v)
+    return out
+
+
+def test_f16x2_calibration_guard(tmp_path, sd_np, built_lib):
+    """The underflow counterpart of the non-finite flag (what's missing 6).  nbc_activation_peaks: the
+    largest stored value of every activation tensor on a real frame.  An ordinary checkpoint keeps every tensor between 2^-8 and
+    2^14 (printed); one whose data breaks its BatchNorm's promise (a tensor at 2^-20) is caught before any batch runs: the
+    folder driver leaves in f16x2 the way it leaves on the non-finite word (--precision auto then takes the f32 MFMA), and
+    fp32 runs the checkpoint."""
+    from neuralbarkcalculator_amd.model import FCNResNet50
+    x = torch.from_numpy(np.stack([synth.make_input(3, 256, 320)])).to("cuda:0")
+    m = FCNResNet50("f16x2").load_state_dict(sd_np).to("cuda:0")
+    peaks = m.activation_peaks(x)
+    ok, bad = FCNResNet50.f16x2_range_ok(peaks)
+    lo, hi = min(peaks.items(), key=lambda kv: kv[1]), max(peaks.items(), key=lambda kv: kv[1])
+    print("ordinary checkpoint: stored peaks from %s %.3g to %s %.3g" % (lo[0], lo[1], hi[0], hi[1]))
+    assert ok and len(peaks) == 54 and lo[1] > 2.0 ** -6 and hi[1] < 2.0 ** 10, bad
+    sd = _stats_do_not_describe_the_data(sd_np)
+    m2 = FCNResNet50("f16x2").load_state_dict(sd).to("cuda:0")
+    assert m2.pack_flags == 0 and m2.activation_exponent("backbone.layer2.1.conv1") == 0     # the packer sees nothing
+    ok2, bad2 = FCNResNet50.f16x2_range_ok(m2.activation_peaks(x))
+    assert not ok2 and "backbone.layer2.1.conv1" in bad2 and bad2["backbone.layer2.1.conv1"] < 2.0 ** -12, bad2
+    assert not m2.nonfinite_seen()                                                            # ... and neither does the flag
+    layout = [("sapin", "a.bmp", 11, 88, 120), ("sapin", "b.bmp", 12, 88, 120)]
+    root = str(tmp_path / "cal")
+    ckpt, _ = _make_folder(root, sd, layout)
+    with pytest.raises(drv.NonFiniteLogits) as e:
+        drv.predict_folder(root, ckpt, precision="f16x2", device_index=0)
+    assert e.value.batches_run == 0 and "calibration" in str(e.value) and "layer2.1.conv1" in str(e.value)
+    st = drv.predict_folder(root, ckpt, precision="fp32", device_index=0)
+    assert st["images_total"] == 2
