@@ -19,7 +19,7 @@ tot = [0.0, 0.0]
 for o in d["ops"]:
     k = o["kernel"]
     m = re.match(r"conv_dma_kernel<2, (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\d+), (\w+)>", k)
-    r = re.match(r"conv3x3_rowstep_kernel<(\d+), (\d+), (\d+)>", k)
+    r = re.match(r"conv3x3_rowstep_kernel<(?:\d+, )?(\d+), (\d+), (\d+)>", k)   # <[PREC,] WN, NT, SB>
     if m and m.group(6) == "false":
         wm, wn, mt, nt = (int(m.group(i)) for i in range(1, 5))
         bm, bn = wm * mt * 32, wn * nt * 32
