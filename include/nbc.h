@@ -242,16 +242,17 @@ int nbc_resize_cubic_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, floa
 int nbc_preprocess_u8(nbc_ctx* ctx, const uint8_t* src_dev, int H, int W, uint8_t* dst_u8_dev, int32_t* row_lit_dev,
                       int out_h, int out_w, void* hip_stream);
 
-/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..19 (pixels x channels): 0 128x64,
+/* Tuning / test knob for the convolution kernel: tile = -1 (per-layer choice) or 0..20 (pixels x channels): 0 128x64,
  * 1 128x128 (4 waves of 64x64, 2 stages, two blocks per CU), 2 256x128, 3 256x256 (bf16), 4 128x128 (4 stages), 5 128x256,
  * 6 256x64, 7 128x64 (2 stages), 8 64x128, 9 / 10 the 8-wave 128x128 / 128x64, 11 the 16-wave 256x128, 12 the 16-wave
  * 256x256 (bf16), 13 the 8-wave 128x128 of 64x32 wave tiles, and f16x2 only: 14 / 15 = 13 / 10 with four loader waves,
  * 16 = 128x128 of four 64x64 waves + four loader waves, 17 = 13 with two stages (two blocks per CU).  f16x2 has no tile
- * 2, 3, 4, 11, 12; f32 no 3, 12.  18 / 19 are the row-resident 3x3 kernel of f16x2 (csrc/conv3x3_rows.hip: an image row x
- * 128 / 64 channels, the row in LDS for its three taps, one barrier per (channel block, kernel row)): the stride-1 3x3
- * layers of 128-pixel-wide maps run on 18 (256 output channels or more) or 19 (64 / 128) AND ON NOTHING ELSE -- their K order
- * (channel block, kh, kw) is the layer's, so a forced or measured tile leaves them where they are -- and no other layer runs
- * on them.  Forced wherever the layer's kind, Cout and the precision allow it; where they do not, the planned tile runs. */
+ * 2, 3, 4, 11, 12; f32 no 3, 12.  18 / 19 / 20 are the row-resident 3x3 kernel of f16x2 (csrc/conv3x3_rows.hip: an image
+ * row x 128 / 64 channels, or two rows x 64 channels, the rows in LDS for their three taps, one barrier per (channel block,
+ * kernel row)): the stride-1 3x3 layers of 128-pixel-wide maps run on 18 or 20 (256 output channels or more: same K order,
+ * same bits on both) or 19 (64 / 128) AND ON NOTHING ELSE -- their K order (channel block, kh, kw) is the layer's, so a
+ * forced or measured generic tile leaves them where they are -- and no other layer runs on them.  Forced wherever the
+ * layer's kind, Cout and the precision allow it; where they do not, the planned tile runs. */
 int nbc_set_conv_tile(nbc_ctx* ctx, int tile);
 
 /* Per-layer tile choice by measurement: runs one forward on x (so that the workspace holds real

@@ -1,5 +1,5 @@
 // 3x3 stride-1 convolution on 128-pixel-wide feature maps in f16x2 (NBC_PREC_F16X2) whose pixel rows STAY IN LDS for the three
-// taps of a kernel row, one barrier per ROW-STEP: layer3 / layer4 conv2 and classifier.0 (tile 18) and layer2.1-3 conv2
+// taps of a kernel row, one barrier per ROW-STEP: layer3 / layer4 conv2 and classifier.0 (tiles 18 and 20) and layer2.1-3 conv2
 // (tile 19) of a 1024-pixel-wide image -- half of the forward's time.
 //
 // Why.  The generic kernel (conv_igemm_dma.hip) fetches, for every K-step (tap, 32-channel block), the 128 pixel rows of its
@@ -15,6 +15,10 @@
 // 128 x 256 tile 48 for twice the outputs), barriers and round trips to a third.
 // Measured (profiles/r05_rows_kernel_*.log, r05_rows_tile18_one_barrier_per_rowstep.log): the head conv 738 -> 680 us,
 // layer4's conv2 187 -> 174, layer3's 57 -> 51, layer2.1-3's 23.5 -> 20.5; the forward +2.9 %.
+// Tile 20 then takes TWO output rows a dilation apart x 64 channels per block: four input rows per channel block serve six (output
+// row, kernel row) pairs and a weight panel is half as wide -- 72 KiB into LDS per output row and channel block where tile 18
+// moves 99; same K order per output, same bits: head conv -2.3 ... -3.1 %, layer4's conv2 -1.4 ... -2.4 %, layer3's -1 %, the forward
+// +1.4 % (profiles/r05_rowstep_two_output_rows.log).
 // (Built, measured and removed on the way, same logs: the same rows with one barrier per K-step -- 128 x 128 with loader waves
 // and a 256 x 128 tile of 64 x 64 wave tiles that halves the weight traffic as well: +2.0 % on the forward, every layer
 // slower than on this kernel; 64 x 64 wave tiles here: +2-4 % time.)
@@ -26,7 +30,7 @@
 // into one chain that joins the running f32 sum every eighth K-step; f32 BN + ReLU epilogue through a per-wave LDS
 // transpose, whole 256-byte row segments stored.
 //
-// LDS: three row slots (slot = kh: a channel block's three kernel rows) of 144 pixels x 128 bytes, their 16-byte chunks
+// LDS: three row slots (slot = kh: a channel block's three kernel rows; tile 20: four, its four input rows) of 144 pixels x 128 bytes, their 16-byte chunks
 // rotated by the pixel index so that a fragment block may start at ANY pixel without bank conflicts (row_off), and two or
 // three stages of three weight panels (one per kw).
 #include <atomic>
@@ -156,12 +160,21 @@ __device__ __forceinline__ void rows_epilogue(const ConvArgs& p, unsigned char* 
 //   tile 18: WN 4 -> 128 channels, eight MFMA waves, SB 2 (150 KiB): 256 output channels or more;
 //   tile 19: WN 2 ->  64 channels, four MFMA waves,  SB 3 (126 KiB): the 64 / 128-channel layers, whose K loop ran at one
 //            LDS-DMA round trip per K-step (DMA and barriers alone: 19-21 of their 21-25 us).
-template <int WN, int NT, int SB>
-__global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_rowstep_kernel(const ConvArgs p) {
+//   tile 20: OR 2, WN 2 -> TWO output rows (oy and oy + dilation: four input rows between them instead of six) x 64 channels,
+//            eight MFMA waves (output row x pixel half x channel half), SB 2 (122 KiB): per output row and channel block 72 KiB
+//            of pixels and weights where tile 18 moves 99; the same K order per output, so the same bits as tile 18.
+template <int WN, int NT, int SB, int OR>
+__global__ __launch_bounds__((2 * WN * OR + 4) * 64, (2 * WN * OR + 4) / 4) void conv3x3_rowstep_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int WM = 2, MT = 2, CW = WM * WN, NW = 4;   // 2 x WN MFMA waves of 64 x (NT * 32), four loader waves
+  static_assert(OR == 1 || (OR == 2 && SB == 2), "two output rows per block: every row-step's DMAs are waited for in full");
+  constexpr int WM = 2, MT = 2, CW = WM * WN * OR, NW = 4;   // 2 x WN (x OR) MFMA waves of 64 x (NT * 32), four loader waves
   constexpr int BN = WN * NT * 32;
-  constexpr int A_SLOT = kRowBytes, A_REGION = 3 * A_SLOT;
+  // pixel-row slots.  OR 1: slot = kh.  OR 2: slot k = input row oy + (k - 1) dil; row-step kh reads slots kh (first output row) and
+  // kh + 1 (second): slots 0 and 1 are requested with kh 0's weights, 2 with kh 1's, 3 with kh 2's, each a row-step ahead, into a slot
+  // last read two row-steps before.  (Rows requested TWO row-steps ahead through a ring of six slots: the same times,
+  // profiles/r05_rowstep_two_output_rows.log.)
+  constexpr int NSLOT = OR == 2 ? 4 : 3;
+  constexpr int A_SLOT = kRowBytes, A_REGION = NSLOT * A_SLOT;
   constexpr int B_TAP = BN * 128, B_STEP = 3 * B_TAP;
   constexpr int TABLE_OFF = A_REGION + SB * B_STEP;   // the ring; the epilogue scratch (18 / 36 KiB) lies inside it
   constexpr int NA = kRowPx / 8;                       // 18 pixel DMAs per row-step
@@ -176,7 +189,10 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
   const int lw = __builtin_amdgcn_readfirstlane((wave - CW) & (NW - 1));
   const bool la_hi = lw < NA % NW;
 
-  const int NH = p.N * p.Ho;
+  const int dil = p.dil;
+  // OR 2: the output rows of an image in pairs (oy, oy + dil): groups of 2 dil rows, `dil` pairs each
+  const int pairs = OR == 2 ? ((p.Ho + 2 * dil - 1) / (2 * dil)) * dil : p.Ho;
+  const int NH = p.N * pairs;
   const int segs = p.Wo / 128;                         // 128-pixel segments per row
   const int tiles_n = p.Co / BN;
   const int tiles_m = NH * segs;
@@ -187,9 +203,10 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   }
   const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
-  const int m0 = tile_m * 128, n0 = tile_n * BN;
+  const int n0 = tile_n * BN;
   const int R = tile_m / segs, seg = tile_m - R * segs;
-  const int img = R / p.Ho, oy = R - img * p.Ho;
+  const int img = R / pairs, pr = R - img * pairs;
+  const int oy = OR == 2 ? (pr / dil) * 2 * dil + pr % dil : pr;    // the (first) output row
 
   const rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
   const rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
@@ -198,7 +215,6 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
   const int T = p.ksteps, RS = 3 * cblocks;
   const unsigned wrow_bytes = (unsigned)T * 128u;
   const unsigned tap_stride = (unsigned)cblocks * 128u;
-  const int dil = p.dil;
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   const unsigned smem_base = (unsigned)(size_t)(lds_u8*)smem;
 
@@ -223,15 +239,20 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
     }
     const int la = la_hi ? LA_HI : LA_LO;
     int i_cb = 0, i_kh = 0, i_sb = 0;                   // the row-step issued next: channel block, kh (= its pixel slot), weight stage
-    auto issue_rowstep = [&]() __attribute__((always_inline)) {
-      const int iy = oy + (i_kh - 1) * dil;
+    auto issue_row = [&](int k, int cb, int slot) __attribute__((always_inline)) {     // input row oy + (k - 1) dil of channel block cb
+      const int iy = oy + (k - 1) * dil;
       const bool rowok = (unsigned)iy < (unsigned)p.Hi;
       const unsigned rowoff = (unsigned)((img * p.Hi + iy) * p.Wi) * (unsigned)pix_bytes;
 #pragma unroll
       for (int d = 0; d < LA_HI; ++d)
         if (d < la)
-          dma16_buf(rowok ? a_col[d] + rowoff : kOutOfRange, xrsrc, smem_base + (unsigned)(i_kh * A_SLOT) + (unsigned)(lw + NW * d) * 1024u,
-                    (unsigned)i_cb * 128u);
+          dma16_buf(rowok ? a_col[d] + rowoff : kOutOfRange, xrsrc, smem_base + (unsigned)(slot * A_SLOT) + (unsigned)(lw + NW * d) * 1024u,
+                    (unsigned)cb * 128u);
+    };
+    auto issue_rowstep = [&]() __attribute__((always_inline)) {
+      if constexpr (OR == 1) issue_row(i_kh, i_cb, i_kh);
+      else if (i_kh == 0) { issue_row(0, i_cb, 0); issue_row(1, i_cb, 1); }
+      else issue_row(i_kh + 1, i_cb, i_kh + 1);
       const unsigned soff = ((unsigned)(3 * i_kh) * (unsigned)cblocks + (unsigned)i_cb) * 128u;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw)
@@ -262,7 +283,7 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
 
   // ---- MFMA waves
   const int r16 = lane & 15, q16 = lane >> 4;
-  const int wm = wave % WM, wn = wave / WM;
+  const int wm = wave % WM, orow = OR == 2 ? (wave / WM) & 1 : 0, wn = wave / (WM * OR);
   auto row_off = [](int pix, int chunk) { return pix * 128 + (((chunk + 2 * ((pix >> 1) & 3)) & 7) << 4); };
   unsigned a_rd[3][2];
 #pragma unroll
@@ -281,7 +302,7 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
 #pragma unroll
       for (int e = 0; e < 4; ++e) { acc16[j][i][e] = 0.f; accI2[j][i][e] = 0.f; }
   const f16x8 kLow = {kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH, kH1UnscaleH};
-  unsigned a_off = 0, b_off = 0;                       // byte offsets of the row-step's pixel slot (kh) and weight stage
+  unsigned a_off = (unsigned)(orow * A_SLOT), b_off = 0;   // byte offsets of the row-step's pixel slot (kh [+ 1]) and weight stage
   int t = 0;
   for (int rs = 0; rs < RS; ++rs) {
     __builtin_amdgcn_s_barrier();
@@ -320,21 +341,23 @@ __global__ __launch_bounds__((2 * WN + 4) * 64, (2 * WN + 4) / 4) void conv3x3_r
         }
       }
     }
-    a_off = a_off == 2u * A_SLOT ? 0u : a_off + (unsigned)A_SLOT;
+    a_off = a_off == (unsigned)((2 + orow) * A_SLOT) ? (unsigned)(orow * A_SLOT) : a_off + (unsigned)A_SLOT;
     b_off = b_off == (unsigned)(SB - 1) * B_STEP ? 0u : b_off + (unsigned)B_STEP;
   }
 #pragma unroll
   for (int n = 0; n < NT16 * MT16; ++n) acc16[n / MT16][n % MT16] += accI2[n / MT16][n % MT16];
   __syncthreads();
-  rows_epilogue<CW, MT, NT, TABLE_OFF>(p, smem, acc16, wave, lane, wm, wn, m0, n0);
+  const int oyw = oy + orow * dil;                     // this wave's output row
+  if (oyw < p.Ho)                                      // (the second row of a last, odd pair lies below the image: nothing to store)
+    rows_epilogue<CW, MT, NT, TABLE_OFF>(p, smem, acc16, wave, lane, wm, wn, ((img * p.Ho + oyw) * segs + seg) * 128, n0);
 }
 
-template <int WN, int NT, int SB>
+template <int WN, int NT, int SB, int OR = 1>
 hipError_t launch_rowstep_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int BN = WN * NT * 32;
-  constexpr int smem = 3 * kRowBytes + SB * 3 * BN * 128 + 2048;
+  constexpr int smem = (OR == 2 ? 4 : 3) * kRowBytes + SB * 3 * BN * 128 + 2048;
   static std::atomic<unsigned long long> attr_done{0};
-  auto kern = &conv3x3_rowstep_kernel<WN, NT, SB>;
+  auto kern = &conv3x3_rowstep_kernel<WN, NT, SB, OR>;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return hipErrorInvalidDevice;
   if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1ull)) {
@@ -343,8 +366,9 @@ hipError_t launch_rowstep_cfg(const ConvArgs& a, hipStream_t s) {
     attr_done.fetch_or(1ull << dev, std::memory_order_release);
   }
   if (a.Co % BN != 0 || a.Wo % 128 != 0) return hipErrorInvalidValue;
-  const int tiles = a.N * a.Ho * (a.Wo / 128) * (a.Co / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3((2 * WN + 4) * 64), smem, s, a);
+  const int pairs = OR == 2 ? ((a.Ho + 2 * a.dil - 1) / (2 * a.dil)) * a.dil : a.Ho;
+  const int tiles = a.N * pairs * (a.Wo / 128) * (a.Co / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3((2 * WN * OR + 4) * 64), smem, s, a);
   return hipGetLastError();
 }
 
@@ -352,7 +376,7 @@ hipError_t launch_rowstep_cfg(const ConvArgs& a, hipStream_t s) {
 
 // Whether a convolution runs on the kernels of this file (f16x2): 3x3, stride 1, padding = dilation <= 8, no identity, and
 //   kind 1: 128-pixel-wide maps, 256 output channels or more (layer3 / layer4 conv2, classifier.0 of a 1024-pixel-wide image):
-//           tile 18;
+//           tile 18 or tile 20 (the same K order and bits; the cost model's default is 20);
 //   kind 2: 128-pixel-wide maps, 64 or 128 output channels (layer2.1-3 conv2): tile 19;
 //   0: neither (the generic kernel).  A property of the layer and its shape: the K order follows from it (the head of this file).
 int conv_rows_kind(int precision, int k, int stride, int pad, int dil, int Hi, int Wi, int Ho, int Wo, int Ci, int Co, bool has_res) {
@@ -365,7 +389,7 @@ int conv_rows_kind(int precision, int k, int stride, int pad, int dil, int Hi, i
 }
 
 // rows_tile (tile id - 18): 0 = one image row x 128 channels (eight 64x32 MFMA waves + four loader waves; kind 1),
-// 1 = one image row x 64 channels (four MFMA + four loader waves; kind 2)
+// 1 = one image row x 64 channels (four MFMA + four loader waves; kind 2), 2 = two image rows x 64 channels (eight + four; kind 1)
 hipError_t launch_conv3x3_rows(const ConvArgs& a, int rows_tile, hipStream_t s) {
   if (a.x_bytes == 0 || a.x_bytes >= kOutOfRange || a.w_bytes == 0 || a.w_bytes >= kOutOfRange) return hipErrorInvalidValue;
   if (a.stem || a.KH != 3 || a.KW != 3 || a.ksteps != 9 * (a.Ci * 4 / 128) ||
@@ -374,6 +398,7 @@ hipError_t launch_conv3x3_rows(const ConvArgs& a, int rows_tile, hipStream_t s) 
   const int kind = conv_rows_kind(2, a.KH, a.stride, a.pad, a.dil, a.Hi, a.Wi, a.Ho, a.Wo, a.Ci, a.Co, a.res != nullptr);
   if (rows_tile == 0 && kind == 1) return launch_rowstep_cfg<4, 1, 2>(a, s);
   if (rows_tile == 1 && kind == 2) return launch_rowstep_cfg<2, 1, 3>(a, s);
+  if (rows_tile == 2 && kind == 1) return launch_rowstep_cfg<2, 1, 2, 2>(a, s);
   return hipErrorInvalidValue;
 }
 

@@ -1132,8 +1132,10 @@ hipError_t launch_tile(const ConvArgs& a, int tile, hipStream_t s) {
 //                                128-pixel-wide maps with 256 output channels or more run on it and on nothing else
 //   19  128x64    row-step kernel (one image row x 64 channels, four MFMA + four loader waves): likewise those with 64 / 128
 //                                output channels (layer2.1-3 conv2; conv_rows_kind)
-constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128};
-constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128, 128, 64};
+//   20  256x64    row-step kernel (TWO image rows, a dilation apart, x 64 channels; eight MFMA + four loader waves): the layers of
+//                                tile 18, same K order and bits, 27 % fewer bytes into LDS per product: their default
+constexpr int kTileRows[CONV_TILE_COUNT] = {128, 128, 256, 256, 128, 128, 256, 128, 64, 128, 128, 256, 256, 128, 128, 128, 128, 128, 128, 128, 256};
+constexpr int kTileCols[CONV_TILE_COUNT] = {64, 128, 128, 256, 128, 256, 64, 64, 128, 128, 64, 128, 256, 128, 128, 64, 128, 128, 128, 64, 64};
 
 }  // namespace
 
@@ -1144,7 +1146,7 @@ int conv_tile_cols(int tile) { return tile >= 0 && tile < CONV_TILE_COUNT ? kTil
 bool conv_tile_ok(int precision, int tile, int Co, int rows_kind) {
   if (tile < 0 || tile >= CONV_TILE_COUNT) return false;
   // the row-resident 3x3 kernel's tiles and the generic ones: never mixed (kind 1: 18; kind 2: 19; kind 0: 0 .. 17)
-  const int tile_kind = tile < CONV_TILE_ROWS_FIRST ? 0 : tile - CONV_TILE_ROWS_FIRST + 1;
+  const int tile_kind = tile < CONV_TILE_ROWS_FIRST ? 0 : tile == 19 ? 2 : 1;      // (kind 1: tiles 18 and 20)
   if (rows_kind != tile_kind) return false;
   if (rows_kind != 0) return precision == 2 && Co % kTileCols[tile] == 0;
   if (precision == 0 && (tile == 3 || tile == 12)) return false;   // the f32 kernel keeps two accumulator sets
@@ -1180,25 +1182,25 @@ struct TileModel {
 constexpr TileModel kTileModel[3] = {
     // f32: 157.3 TF / 256 CUs
     {157.3e6 / 256.0,
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
-     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {0.85, 0.85, 0.85, 0.85, 0.85, 0.896, 0.722, 0.811, 0.894, 0.85, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 5.08, 3.14, 0.76, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
     // bf16: against the 1 400 TF/s the chip sustains on this kernel (power-limited), / 256 CUs
     {1400.0e6 / 256.0,
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
-     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
-     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0},
-     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {0.888, 0.85, 0.85, 0.897, 0.85, 0.911, 0.85, 0.85, 0.85, 0.754, 0.85, 0.85, 0.85, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80, 0.80},
+     {1.19, 4.0, 4.0, 2.78, 4.0, 4.0, 4.0, 0.0, 4.0, 0.5, 4.0, 4.0, 3.61, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0, 4.0},
+     {0.91, 1.0, 1.0, 1.07, 1.0, 0.78, 1.0, 1.03, 1.0, 0.68, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0},
+     {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}},
     // f16x2: f32-equivalent FLOPs against the 839 TF/s three f16 MFMAs per product allow (2 517 / 3), / 256 CUs
     {839.0e6 / 256.0,
-     {0.421, 0.52, 0.5, 0.5, 0.5, 0.535, 0.42, 0.476, 0.42, 0.42, 0.455, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.501, 0.50, 0.45},
-     {0.38, 0.36, 0.5, 0.5, 0.5, 0.535, 0.42, 0.383, 0.36, 0.42, 0.392, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.36, 0.50, 0.45},
-     {3, 3, 3, 3, 3, 3.45, 3.007, 3, 2.746, 3, 2.868, 3, 3, 2.518, 3.874, 3, 3, 3.321, 4.0, 3.0},
-     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.309, 0.31, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.195, 0.2, 0.3},
-     {2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1}}};
+     {0.421, 0.52, 0.5, 0.5, 0.5, 0.535, 0.42, 0.476, 0.42, 0.42, 0.455, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.501, 0.50, 0.45, 0.515},
+     {0.38, 0.36, 0.5, 0.5, 0.5, 0.535, 0.42, 0.383, 0.36, 0.42, 0.392, 0.5, 0.5, 0.44, 0.47, 0.4, 0.448, 0.36, 0.50, 0.45, 0.515},
+     {3, 3, 3, 3, 3, 3.45, 3.007, 3, 2.746, 3, 2.868, 3, 3, 2.518, 3.874, 3, 3, 3.321, 4.0, 3.0, 4.0},
+     {0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.309, 0.31, 0.272, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.3, 0.195, 0.2, 0.3, 0.2},
+     {2, 2, 1, 1, 1, 1, 1, 3, 3, 1, 2, 1, 1, 1, 1, 1, 1, 2, 1, 1, 1}}};
 }  // namespace
 
 int choose_conv_tile(int M, int Co, int K, int precision, int rows_kind) {
@@ -1216,8 +1218,10 @@ int choose_conv_tile(int M, int Co, int K, int precision, int rows_kind) {
     const long long g = b / cap, rest = b % cap;
     const double eff_r = cap > 1 && rest > 0 ? tm.eff1[t] + (tm.eff[t] - tm.eff1[t]) * (double)(rest - 1) / (double)(cap - 1) : tm.eff[t];
     const double flops = trows * cols * 2.0 * K;
-    // operand panels per block: the row-resident kernel fetches a pixel row once for the three taps of a kernel row
-    const double bytes = (t >= CONV_TILE_ROWS_FIRST ? trows / 3.0 * 1.125 + cols : trows + cols) * K * eb + trows * cols * eb * 2.0;
+    // operand panels per block: the row-resident kernel fetches a pixel row (144 pixels for 128) once for the three taps of a kernel
+    // row, its two-row tile four rows per channel block for the six (row, kernel row) pairs
+    const double prows = t == 20 ? trows / 4.0 * 1.125 : t >= CONV_TILE_ROWS_FIRST ? trows / 3.0 * 1.125 : trows;
+    const double bytes = (prows + cols) * K * eb + trows * cols * eb * 2.0;
     const double cost = ((double)(g * cap) / tm.eff[t] + (double)rest / eff_r) * flops / tm.cu_flops_per_us +
                         (double)b * bytes * tm.cb[t] / 50.0e3 + (double)((b + cap - 1) / cap) * tm.ovh_us[t];
     // ties (to 1e-9 relative) go to the larger tile: fewer L2 -> LDS bytes per FLOP

@@ -34,8 +34,8 @@ struct ConvArgs {
 // precision: 0 = f32 (v_mfma_f32_32x32x2_f32), 1 = bf16 (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16),
 // 2 = f16x2 (two f16 pieces per f32 value, three v_mfma_f32_16x16x32_f16 per product: split16.hpp)
 // LDS-DMA ring (conv_igemm_dma.hip).  tile < 0 = choose_conv_tile(M, Co, K, precision).
-constexpr int CONV_TILE_COUNT = 20;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19 = the row-resident 3x3 kernel
-constexpr int CONV_TILE_ROWS_FIRST = 18;   // (conv3x3_rows.hip: one image row x 128 / 64 channels)
+constexpr int CONV_TILE_COUNT = 21;   // tile menu: see launch_tile() in conv_igemm_dma.hip; 18, 19, 20 = the row-resident 3x3 kernel
+constexpr int CONV_TILE_ROWS_FIRST = 18;   // (conv3x3_rows.hip: one image row x 128 / 64 channels; 20: two rows x 64 channels)
 int conv_tile_rows(int tile);
 int conv_tile_cols(int tile);
 // Whether a convolution runs on the row-resident 3x3 kernels (conv3x3_rows.hip; f16x2, 3x3, stride 1, no identity): 0 no;

@@ -371,7 +371,7 @@ class FCNResNet50:
             _lib.check(self._lib.nbc_nonfinite_peek_async(self._require_ctx(), host_word.data_ptr(), stream), "nbc_nonfinite_peek_async")
 
     def set_conv_tile(self, tile: int = -1):
-        """Tuning/test knob: tile -1 = per-layer choice, 0..19 = one tile shape of the conv kernel (18 / 19: the row-resident 3x3
+        """Tuning/test knob: tile -1 = per-layer choice, 0..20 = one tile shape of the conv kernel (18 / 19 / 20: the row-resident 3x3
         kernel of f16x2, which its layers never leave; the menu:
         include/nbc.h, nbc_set_conv_tile; e.g. 5 = 128x256, 14 = 128x128 with four loader waves and 17 = 128x128 at two
         blocks per CU, both f16x2 only).  A tile that does not exist for the precision, or does not divide a layer's
