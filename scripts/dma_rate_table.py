@@ -19,21 +19,23 @@ tot = [0.0, 0.0]
 for o in d["ops"]:
     k = o["kernel"]
     m = re.match(r"conv_dma_kernel<2, (\d+), (\d+), (\d+), (\d+), (\d+), (\w+), (\d+), (\w+)>", k)
-    r = re.match(r"conv3x3_rowstep_kernel<(?:\d+, )?(\d+), (\d+), (\d+)>", k)   # <[PREC,] WN, NT, SB>
+    r = re.match(r"conv3x3_rowstep_kernel<([\d, ]+)>", k)          # <WN, NT, SB[, OR]>: OR output rows per block
     if m and m.group(6) == "false":
         wm, wn, mt, nt = (int(m.group(i)) for i in range(1, 5))
-        bm, bn = wm * mt * 32, wn * nt * 32
+        bm, bn, orows = wm * mt * 32, wn * nt * 32, 0
     elif r:
-        bm, bn = 128, int(r.group(1)) * 32 * int(r.group(2))
+        a = [int(v) for v in r.group(1).split(",")]
+        orows = a[3] if len(a) > 3 else 1
+        bm, bn = 128 * orows, a[0] * 32 * a[1]
     else:
         continue
     co = o["cout"]
     pixels = o["grid"] * bm * bn / co
     K = o["flops"] / (2 * pixels * co)
-    if m:
+    if orows == 0:
         per_block = K / 32 * (bm + bn) * 128                      # a K-step: BM pixel rows + BN weight rows of 128 bytes
-    else:
-        per_block = K / 32 / 3 * (144 * 128 + 3 * bn * 128)       # a row-step: one 144-pixel row slot + three taps' weight rows
+    else:                                                         # a channel block: orows + 2 row slots of 144 pixels + nine taps' weight rows
+        per_block = K / 32 / 9 * ((orows + 2) * 144 * 128 + 9 * bn * 128)
     per_cu = per_block * o["grid"] / 256
     model = o["flops"] / peak * 1e6 + per_cu / (dma_only * 1e3)
     tot[0] += o["median_us"]
