@@ -72,6 +72,14 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
       : "v"(gsrc), "s"(lds_base)
       : "memory");
 }
+// Tile 20: the output rows of an image in pairs (oy, oy + dil): whole groups of 2 dil rows hold dil pairs each (pair q of group g: rows
+// g 2 dil + q and + dil), a last group of fewer rows one pair per row of its first half (the second row of such a pair may lie below
+// the image: computed on zero rows, not stored).  Pair index -> first row: (pr / dil) 2 dil + pr % dil in both cases.
+__host__ __device__ inline int rowstep_pairs(int Ho, int dil) {
+  const int groups = Ho / (2 * dil), rem = Ho - groups * 2 * dil;
+  return groups * dil + (rem < dil ? rem : dil);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -190,8 +198,8 @@ __global__ __launch_bounds__((2 * WN * OR + 4) * 64, (2 * WN * OR + 4) / 4) void
   const bool la_hi = lw < NA % NW;
 
   const int dil = p.dil;
-  // OR 2: the output rows of an image in pairs (oy, oy + dil): groups of 2 dil rows, `dil` pairs each
-  const int pairs = OR == 2 ? ((p.Ho + 2 * dil - 1) / (2 * dil)) * dil : p.Ho;
+  // OR 2: the output rows of an image in pairs (oy, oy + dil): rowstep_pairs
+  const int pairs = OR == 2 ? rowstep_pairs(p.Ho, dil) : p.Ho;
   const int NH = p.N * pairs;
   const int segs = p.Wo / 128;                         // 128-pixel segments per row
   const int tiles_n = p.Co / BN;
@@ -366,7 +374,7 @@ hipError_t launch_rowstep_cfg(const ConvArgs& a, hipStream_t s) {
     attr_done.fetch_or(1ull << dev, std::memory_order_release);
   }
   if (a.Co % BN != 0 || a.Wo % 128 != 0) return hipErrorInvalidValue;
-  const int pairs = OR == 2 ? ((a.Ho + 2 * a.dil - 1) / (2 * a.dil)) * a.dil : a.Ho;
+  const int pairs = OR == 2 ? rowstep_pairs(a.Ho, a.dil) : a.Ho;
   const int tiles = a.N * pairs * (a.Wo / 128) * (a.Co / BN);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3((2 * WN * OR + 4) * 64), smem, s, a);
   return hipGetLastError();

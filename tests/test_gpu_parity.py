@@ -133,15 +133,16 @@ def test_every_conv_unit_with_rescaled_activations(built_lib, sd_np):
         assert not model.nonfinite_seen()
 
 
-@pytest.mark.parametrize("shape", [(1, 72, 1024), (2, 40, 1024), (1, 8, 1024), (3, 24, 1024)])
+@pytest.mark.parametrize("shape", [(1, 72, 1024), (2, 40, 1024), (1, 8, 1024), (3, 24, 1024), (1, 200, 1024)])
 def test_row_resident_3x3_kernel_layer_by_layer(oracle_model, built_lib, sd_np, shape):
     """The stride-1 3x3 layers of a 1024-pixel-wide image (128-pixel-wide maps from layer2 on) run in "f16x2" on the
     row-resident kernel (csrc/conv3x3_rows.hip: a pixel row fetched once for the three taps of a kernel row, one barrier per
     (channel block, kh), K order (channel block, kh, kw)): layer3 / layer4 conv2 at dilation 1, 2 and 4 and classifier.0 on
     tile 18 (an image row x 128 channels per block) or tile 20 (two rows, a dilation apart, x 64 channels: the same K order, the
     same bits), layer2.1-3 conv2 on tile 19 (64).  Every conv unit against the oracle under the layer
-    tolerance on shapes that exercise its edges: an odd number of map rows, batches (every image row is a tile of its own: rows
-    of different images side by side), a map of ONE row (every dilated tap row outside the image); and a forced generic tile
+    tolerance on shapes that exercise its edges: an odd number of map rows (tile 20 pairs rows a dilation apart inside groups of
+    2 x dilation rows: 9, 5, 3, 1 and 25 rows leave a last group with a single row at dilation 1, 2 and 4), batches (every image row
+    is a tile of its own: rows of different images side by side), a map of ONE row (every dilated tap row outside the image); and a forced generic tile
     changes nothing on these layers -- the K order is the layer's, not the tile's -- while every other layer still takes it."""
     from oracle.fcn_resnet50_oracle import layer_outputs
     n, h, w = shape
